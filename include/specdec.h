@@ -1,0 +1,180 @@
+/*
+ * specdec.h - C ABI of libspecdec.so, the MI355X (gfx950) speculative-sampling decode engine.
+ *
+ * The reference (ZongyueQin/LLMSpeculativeSampling) exposes this path as a Python API with no
+ * FFI; the entry points below are what a binding for that path binds.
+ * Each one names the reference code it replaces (file:line under the reference repo).
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers, explicit sizes, a hipStream_t passed as void*.
+ *   - every function returns 0 on success or a negative sd_status; sd_last_error() gives the text.
+ *   - the library never owns caller memory: weights, KV arenas, probability arenas and scratch
+ *     are allocated by the caller and handed over as pointers; handles own only host structs.
+ *   - nothing here synchronises the stream unless its comment says so.
+ */
+#ifndef SPECDEC_H
+#define SPECDEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_ABI_VERSION 1
+
+typedef enum {
+    SD_OK = 0,
+    SD_ERR_INVALID = -1,      /* bad argument / unsupported shape                                  */
+    SD_ERR_NORM_LOGITS = -2,  /* RuntimeError('norm logits error')   reference utils.py:203-207    */
+    SD_ERR_PROB = -3,         /* RuntimeError('prob error')          reference utils.py:220-224    */
+    SD_ERR_HIP = -4,          /* a HIP runtime call failed                                         */
+    SD_ERR_CAPACITY = -5      /* sequence / row count beyond what the session was sized for        */
+} sd_status;
+
+typedef enum { SD_F32 = 0, SD_BF16 = 1 } sd_dtype;
+typedef enum { SD_ARCH_LLAMA = 0, SD_ARCH_OPT = 1 } sd_arch;
+
+int sd_version(void);
+const char *sd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampling primitives                                            reference sampling/utils.py
+ * ------------------------------------------------------------------------------------------ */
+
+/* norm_logits + top_k_top_p_filter (utils.py:182-210, 152-179), one workgroup per row:
+ * logits/temperature -> keep >= k-th largest (ties kept) -> stable descending order, drop
+ * everything after the first token whose cumulative softmax mass exceeds top_p ->
+ * exp(log_softmax).  rows are `ld_*` elements apart.  err_flag[row] (device int, may be NULL)
+ * is set to 1 where the reference would raise 'norm logits error' (NaN/Inf result).
+ * bf16_round_logits != 0 rounds each fp32 logit to bf16 first (a bf16 lm_head whose output the
+ * reference then casts with .float(), modeling_llama.py:869-870). */
+int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
+                  float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
+                  void *stream);
+
+/* sample (utils.py:213-233) for num_samples == 1: argmax_i probs[i] / noise[i] (first index wins
+ * ties), then the "< 1e-9 -> argmax(probs)" fix-up.  exp_noise is a device row of Exp(1) variates
+ * in the reference's draw order (parity mode), or NULL to draw them on the device from Philox
+ * (seed, draw_index).  tok_out: device int32.  err_flag (device, may be NULL): 1 = invalid
+ * distribution (negative / NaN / Inf), 2 = all-zero row; both are 'prob error' in the reference. */
+int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,
+              uint64_t draw_index, int *tok_out, int *err_flag, void *stream);
+
+/* max_fn (utils.py:236-245) materialised: out = max(p-q,0) / (sum(max(p-q,0)) + 1e-6).  q may be
+ * NULL (then max_fn(p)).  Only the drop-in sampling.utils.max_fn uses this; the decode loop uses
+ * the fused sd_resample below and never writes the residual row. */
+int sd_max_fn(const float *p, const float *q, int V, float *out, void *stream);
+
+/* Result block written by the accept / resample kernels (device or pinned-host memory). */
+typedef struct {
+    int32_t n_accepted;    /* l: drafted tokens accepted this iteration   (speculative_sampling.py:1974-1991) */
+    int32_t n;             /* last kept position, L+l-1                    (:1964, :1983)                      */
+    int32_t next_token;    /* t: residual resample or bonus sample         (:2005-2023)                        */
+    int32_t flags;         /* bit0 residual was all-zero -> fallback sample(max_fn(p_n)) (:2009-2010);
+                              bit1 'prob error'; bit2 all gamma accepted                                       */
+    float p_at[16];        /* target prob of each drafted token (for the acc_rate statistic, :1966-1971)      */
+    float q_at[16];        /* draft prob of each drafted token                                                */
+} sd_accept_result;
+
+/* Accept scan (speculative_sampling.py:1964-1991): for i < gamma, j = seq[L+i]; reject iff
+ * r[i] > float32(double(p_hist[L+i-1][j]) / double(q_hist[L+i-1][j])); the first reject decides.
+ * p_hist / q_hist are probability arenas indexed by absolute position (row stride ld).  r: gamma
+ * device floats in the reference's draw order (parity mode; the caller re-aligns the host generator
+ * to the min(l+1, gamma) uniforms the reference would have consumed), or NULL for device Philox
+ * (seed, draw_index + i).  Writes n_accepted, n, p_at, q_at, flags bit2; next_token = -1. */
+int sd_accept_scan(const float *p_hist, const float *q_hist, long ld, const int32_t *seq, int L,
+                   int gamma, const float *r, uint64_t philox_seed, uint64_t draw_index,
+                   sd_accept_result *out, void *stream);
+
+/* Residual resample / bonus sample (speculative_sampling.py:2005-2023) at position res->n, read
+ * from the device result block: rejected -> sample(max_fn(p_n - q_n)) with the all-zero fallback
+ * sample(max_fn(p_n)); all accepted -> sample(p_last).  Writes next_token and flags, appends the
+ * token at seq[n+1] and stores the new sequence length n+2 into *seq_len (device int, may be NULL). */
+int sd_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L,
+                int gamma, const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
+                sd_accept_result *res, int32_t *seq_len, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder model + KV arena           reference sampling/models/modeling_{llama,opt}.py,
+ *                                    sampling/kvcache_model.py:141-252 (forward), :359-436 (rollback)
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+    int32_t arch;                 /* sd_arch                                                    */
+    int32_t dtype;                /* sd_dtype of weights and activations                        */
+    int32_t vocab, hidden, inter, n_layers, n_heads, n_kv_heads, head_dim;
+    int32_t max_pos;              /* rows of the rope table (llama) / learned positions (opt)   */
+    int32_t opt_pre_ln;           /* OPT do_layer_norm_before (125m/13b: 1, 350m: 0)            */
+    int32_t opt_proj_dim;         /* OPT word_embed_proj_dim (== hidden when no project_in/out) */
+    float norm_eps;
+    int32_t logits_bf16_round;    /* round logits to bf16 before use (bf16 lm_head semantics)   */
+} sd_model_config;
+
+/* Weight table.  Matrices are [out][in] as in nn.Linear.  For dtype SD_BF16 every GEMM matrix is
+ * handed over in the tile-packed layout produced by sd_pack_weight_bf16 ("HBM
+ * layout"); for SD_F32 they stay row-major.  Vectors / embeddings are row-major in `dtype`.
+ * Per-layer arrays have n_layers entries.  Unused entries are NULL. */
+typedef struct {
+    const void *embed;            /* [vocab][embed_dim] row-major                               */
+    const void *pos_embed;        /* OPT: [max_pos+2][hidden]                                   */
+    const void *project_in;       /* OPT 350m: [hidden][proj]   (GEMM matrix)                   */
+    const void *project_out;      /* OPT 350m: [proj][hidden]   (GEMM matrix)                   */
+    const void *final_norm_w, *final_norm_b;
+    const void *lm_head;          /* [vocab][embed_dim]         (GEMM matrix)                   */
+    const void *rope_cos, *rope_sin; /* llama: [max_pos][head_dim/2] in `dtype`                 */
+    const void *const *wqkv;      /* [(n_heads+2*n_kv_heads)*head_dim][hidden], q rows then k then v */
+    const void *const *bqkv;      /* OPT biases, same order                                     */
+    const void *const *wo;        /* [hidden][hidden]                                           */
+    const void *const *bo;
+    const void *const *w_gate_up; /* llama: [2*inter][hidden], gate rows then up rows; OPT fc1: [inter][hidden] */
+    const void *const *b_fc1;
+    const void *const *w_down;    /* [hidden][inter] (OPT fc2)                                  */
+    const void *const *b_fc2;
+    const void *const *norm1_w, *const *norm1_b;  /* input_layernorm / self_attn_layer_norm      */
+    const void *const *norm2_w, *const *norm2_b;  /* post_attention_layernorm / final_layer_norm */
+} sd_model_weights;
+
+typedef struct sd_model sd_model;
+
+/* Copies the config and the pointer table into a host handle (weights stay where they are). */
+int sd_model_create(const sd_model_config *cfg, const sd_model_weights *w, sd_model **out);
+int sd_model_destroy(sd_model *m);
+
+/* Repack a row-major bf16 [N][K] matrix (N % 16 == 0, K % 32 == 0) into the streaming layout the
+ * GEMM kernels read: 1 KiB tiles [N/16][K/32][lane 0..63][8 bf16], lane = 16*(k/8 % 4) + n % 16. */
+int sd_pack_weight_bf16(const void *w_rowmajor, void *w_packed, int N, int K, void *stream);
+
+/* A session = one KV arena + scratch for one sequence (one KVCacheModel of the reference).
+ * kv_arena: [n_layers][2][n_kv_heads][max_seq][head_dim] in `dtype`, caller-allocated.
+ * scratch: sd_session_scratch_bytes() bytes, caller-allocated. */
+typedef struct sd_session sd_session;
+size_t sd_session_kv_bytes(const sd_model *m, int max_seq);
+size_t sd_session_scratch_bytes(const sd_model *m, int max_rows);
+int sd_session_create(sd_model *m, int max_seq, int max_rows, void *kv_arena, void *scratch,
+                      sd_session **out);
+int sd_session_destroy(sd_session *s);
+
+/* One model forward over n_new tokens at absolute positions pos0 .. pos0+n_new-1, appending their
+ * K/V rows into the arena in-kernel (replaces the per-layer torch.cat of modeling_llama.py:337-338 /
+ * modeling_opt.py:192-193 and kvcache_model.py:214).  tokens: device int32, read at tokens[0..n_new).
+ * Logits (fp32) are produced for the LAST n_logits of the new rows into logits_out[n_logits][vocab]
+ * (row stride ld_logits); n_logits == 0 skips the head.  Rollback is O(1): the caller just passes a
+ * smaller pos0 next time (kvcache_model.py:359-436).  n_new <= max_rows, pos0+n_new <= max_seq. */
+int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
+                       float *logits_out, long ld_logits, void *stream);
+
+/* Per-op-class timing for the roofline report: when enabled, every launch inside
+ * sd_session_forward is bracketed with HIP events on the launch stream; sd_profile_read
+ * synchronises the stream, returns accumulated milliseconds and launch counts per class, and
+ * resets them.  Classes: 0 gemm, 1 attention, 2 norm/residual epilogues, 3 qkv-rope-append,
+ * 4 activation, 5 embed, 6 logits epilogue. */
+#define SD_N_PROFILE_CLASSES 8
+int sd_profile_enable(sd_session *s, int on);
+int sd_profile_read(sd_session *s, float *ms_out, int *count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECDEC_H */

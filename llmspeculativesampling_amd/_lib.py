@@ -1,0 +1,102 @@
+"""ctypes binding of libspecdec.so (the C ABI declared in include/specdec.h).
+
+There is no CPU fallback: if the shared object is missing or fails to load the
+import raises, and every entry point converts a negative sd_status into the
+Python exception the reference raises at the same place (Errors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspecdec.so")
+
+SD_OK, SD_ERR_INVALID, SD_ERR_NORM_LOGITS, SD_ERR_PROB, SD_ERR_HIP, SD_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
+SD_F32, SD_BF16 = 0, 1
+N_PROFILE_CLASSES = 8
+PROFILE_CLASS_NAMES = ["gemm", "attention", "norm_residual", "qkv_rope_append", "activation", "embed",
+                       "logits", "other"]
+
+
+class SdAcceptResult(C.Structure):
+    _fields_ = [("n_accepted", C.c_int32), ("n", C.c_int32), ("next_token", C.c_int32), ("flags", C.c_int32),
+                ("p_at", C.c_float * 16), ("q_at", C.c_float * 16)]
+
+
+class SdModelConfig(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("dtype", C.c_int32), ("vocab", C.c_int32), ("hidden", C.c_int32),
+                ("inter", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("max_pos", C.c_int32), ("opt_pre_ln", C.c_int32),
+                ("opt_proj_dim", C.c_int32), ("norm_eps", C.c_float), ("logits_bf16_round", C.c_int32)]
+
+
+_VP = C.c_void_p
+_VPP = C.POINTER(C.c_void_p)
+
+
+class SdModelWeights(C.Structure):
+    _fields_ = [("embed", _VP), ("pos_embed", _VP), ("project_in", _VP), ("project_out", _VP),
+                ("final_norm_w", _VP), ("final_norm_b", _VP), ("lm_head", _VP), ("rope_cos", _VP), ("rope_sin", _VP),
+                ("wqkv", _VPP), ("bqkv", _VPP), ("wo", _VPP), ("bo", _VPP), ("w_gate_up", _VPP), ("b_fc1", _VPP),
+                ("w_down", _VPP), ("b_fc2", _VPP), ("norm1_w", _VPP), ("norm1_b", _VPP), ("norm2_w", _VPP),
+                ("norm2_b", _VPP)]
+
+
+# every symbol include/specdec.h declares: (name, restype, argtypes)
+_F, _I, _L, _U64 = C.c_float, C.c_int, C.c_long, C.c_uint64
+SYMBOLS = [
+    ("sd_version", _I, []),
+    ("sd_last_error", C.c_char_p, []),
+    ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP]),
+    ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
+    ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),
+    ("sd_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_model_create", _I, [C.POINTER(SdModelConfig), C.POINTER(SdModelWeights), C.POINTER(_VP)]),
+    ("sd_model_destroy", _I, [_VP]),
+    ("sd_pack_weight_bf16", _I, [_VP, _VP, _I, _I, _VP]),
+    ("sd_session_kv_bytes", C.c_size_t, [_VP, _I]),
+    ("sd_session_scratch_bytes", C.c_size_t, [_VP, _I]),
+    ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),
+    ("sd_session_destroy", _I, [_VP]),
+    ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
+    ("sd_profile_enable", _I, [_VP, _I]),
+    ("sd_profile_read", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m llmspeculativesampling_amd._build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class SpecDecError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    """Negative sd_status -> the reference's exception at that point."""
+    if rc == SD_OK:
+        return
+    msg = lib.sd_last_error().decode(errors="replace")
+    if rc == SD_ERR_NORM_LOGITS:
+        raise RuntimeError("norm logits error")          # reference utils.py:207
+    if rc == SD_ERR_PROB:
+        raise RuntimeError("prob error")                 # reference utils.py:224
+    if rc == SD_ERR_CAPACITY:
+        raise SpecDecError(f"{what}: capacity exceeded: {msg}")
+    if rc == SD_ERR_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    raise SpecDecError(f"{what}: HIP failure: {msg}")

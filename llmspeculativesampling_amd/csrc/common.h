@@ -1,0 +1,79 @@
+// Shared helpers for libspecdec (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/specdec.h"
+
+typedef __bf16 bf16_t;
+
+void sd_set_error(const char *fmt, ...);
+
+#define SD_HIP_CHECK(expr)                                                             \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            sd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SD_ERR_HIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+#define SD_REQUIRE(cond, ...)                                                          \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            sd_set_error(__VA_ARGS__);                                                 \
+            return SD_ERR_INVALID;                                                     \
+        }                                                                              \
+    } while (0)
+
+#define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
+
+// ---- activation dtype helpers: T is float or bf16_t.  rnd<T>(x) rounds an fp32 value to the
+// storage type and back, which is how every per-op result of a bf16 reference model is rounded.
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+template <typename T> __device__ __forceinline__ float rnd(float x) { return to_f(from_f<T>(x)); }
+
+// ---- wave / block reductions (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum / max through a small LDS array (>= 16 floats); all threads get the result.
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float *sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}

@@ -1,0 +1,461 @@
+// Host side of the decoder engine: model / session handles and the per-forward launch chain.
+// Replaces (for one sequence) reference sampling/kvcache_model.py:141-252 -> model forward
+// (modeling_llama.py:624-768 / modeling_opt.py:561-759) with a fixed chain of HIP launches over
+// a preallocated KV arena; rollback (kvcache_model.py:359-436) is the caller passing a smaller pos0.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "model_kernels.h"
+
+static thread_local char g_err[512] = "";
+void sd_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *sd_last_error(void) { return g_err; }
+extern "C" int sd_version(void) { return SD_ABI_VERSION; }
+
+struct sd_model {
+    sd_model_config cfg;
+    sd_model_weights w;
+    std::vector<const void *> wqkv, bqkv, wo, bo, wgu, bfc1, wdown, bfc2, n1w, n1b, n2w, n2b;
+};
+
+enum { PC_GEMM = 0, PC_ATTN, PC_NORM, PC_QKV, PC_ACT, PC_EMBED, PC_LOGITS, PC_OTHER };
+
+struct sd_session {
+    sd_model *m;
+    int max_seq, max_rows;
+    char *kv;        // [L][2][Hkv][max_seq][D]
+    char *scratch;
+    // carved scratch
+    void *x, *h, *qbuf, *attn, *act, *ebuf;
+    float *part;
+    size_t part_floats;
+    // profiling
+    int prof_on;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_class;
+    size_t ev_used;
+    float prof_ms[SD_N_PROFILE_CLASSES];
+    int prof_cnt[SD_N_PROFILE_CLASSES];
+    hipStream_t prof_stream;
+};
+
+static inline size_t esize(int dtype) { return dtype == SD_BF16 ? 2 : 4; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void copy_ptrs(std::vector<const void *> &dst, const void *const *src, int n) {
+    dst.assign(n, nullptr);
+    if (src)
+        for (int i = 0; i < n; ++i) dst[i] = src[i];
+}
+
+extern "C" int sd_model_create(const sd_model_config *cfg, const sd_model_weights *w, sd_model **out) {
+    SD_REQUIRE(cfg && w && out, "sd_model_create: null argument");
+    SD_REQUIRE(cfg->arch == SD_ARCH_LLAMA || cfg->arch == SD_ARCH_OPT, "sd_model_create: unknown arch %d", cfg->arch);
+    SD_REQUIRE(cfg->dtype == SD_F32 || cfg->dtype == SD_BF16, "sd_model_create: unknown dtype %d", cfg->dtype);
+    SD_REQUIRE(cfg->head_dim == 16 || cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128,
+               "sd_model_create: head_dim %d not in {16,32,64,128}", cfg->head_dim);
+    SD_REQUIRE(cfg->n_heads * cfg->head_dim == cfg->hidden, "sd_model_create: n_heads*head_dim != hidden");
+    SD_REQUIRE(cfg->n_kv_heads > 0 && cfg->n_heads % cfg->n_kv_heads == 0, "sd_model_create: bad n_kv_heads");
+    if (cfg->dtype == SD_BF16) {
+        SD_REQUIRE(cfg->hidden % 32 == 0 && cfg->inter % 32 == 0 && cfg->vocab % 16 == 0 && cfg->opt_proj_dim % 32 == 0,
+                   "sd_model_create: bf16 path needs hidden/inter/proj %% 32 == 0 and vocab %% 16 == 0");
+    }
+    SD_REQUIRE(w->embed && w->lm_head && w->wqkv && w->wo && w->w_gate_up && w->w_down && w->norm1_w && w->norm2_w,
+               "sd_model_create: missing weight pointers");
+    sd_model *m = new sd_model();
+    m->cfg = *cfg;
+    m->w = *w;
+    const int L = cfg->n_layers;
+    copy_ptrs(m->wqkv, w->wqkv, L); copy_ptrs(m->bqkv, w->bqkv, L);
+    copy_ptrs(m->wo, w->wo, L); copy_ptrs(m->bo, w->bo, L);
+    copy_ptrs(m->wgu, w->w_gate_up, L); copy_ptrs(m->bfc1, w->b_fc1, L);
+    copy_ptrs(m->wdown, w->w_down, L); copy_ptrs(m->bfc2, w->b_fc2, L);
+    copy_ptrs(m->n1w, w->norm1_w, L); copy_ptrs(m->n1b, w->norm1_b, L);
+    copy_ptrs(m->n2w, w->norm2_w, L); copy_ptrs(m->n2b, w->norm2_b, L);
+    *out = m;
+    return SD_OK;
+}
+
+extern "C" int sd_model_destroy(sd_model *m) {
+    delete m;
+    return SD_OK;
+}
+
+extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, void *stream) {
+    SD_REQUIRE(src && dst && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0,
+               "sd_pack_weight_bf16: need N %% 16 == 0 and K %% 32 == 0 (got %d x %d)", N, K);
+    const size_t total = (size_t)N * K / 8;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)src,
+                       (uint16_t *)dst, N, K);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// ---- split-K policy: enough (n-tile, k-slice) units to keep >= ~16 waves per CU streaming
+static void gemm_split(int N, int K, int *S_out, int *ks_per_out) {
+    const int NTL = N / 16, KS = K / 32;
+    int S = (4096 + NTL - 1) / NTL;
+    const char *env = getenv("SD_GEMM_UNITS");
+    if (env) S = (atoi(env) + NTL - 1) / NTL;
+    if (S < 1) S = 1;
+    int max_s = KS / 4;                      // at least 4 k-steps (4 KiB of weights) per unit
+    if (max_s < 1) max_s = 1;
+    if (S > max_s) S = max_s;
+    int ks_per = (KS + S - 1) / S;
+    S = (KS + ks_per - 1) / ks_per;
+    *S_out = S;
+    *ks_per_out = ks_per;
+}
+
+static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
+    if (c.dtype != SD_BF16) return (size_t)rows * N;
+    int S, ksp;
+    gemm_split(N, K, &S, &ksp);
+    return (size_t)S * align_up(rows, 16) * N;
+}
+
+static int qkv_cols(const sd_model_config &c) { return (c.n_heads + 2 * c.n_kv_heads) * c.head_dim; }
+static int gu_cols(const sd_model_config &c) { return c.arch == SD_ARCH_LLAMA ? 2 * c.inter : c.inter; }
+static int embed_dim(const sd_model_config &c) { return c.arch == SD_ARCH_OPT ? c.opt_proj_dim : c.hidden; }
+
+extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
+    const sd_model_config &c = m->cfg;
+    return (size_t)c.n_layers * 2 * c.n_kv_heads * max_seq * c.head_dim * esize(c.dtype);
+}
+
+struct ScratchPlan {
+    size_t x, h, q, attn, act, e, part, total, part_floats;
+};
+static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
+    ScratchPlan p;
+    const size_t es = esize(c.dtype);
+    const int ed = embed_dim(c);
+    const int wide = std::max(c.hidden, ed);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    p.x = take((size_t)rows * c.hidden * es);
+    p.h = take((size_t)rows * wide * es);
+    p.q = take((size_t)rows * c.hidden * es);
+    p.attn = take((size_t)rows * c.hidden * es);
+    p.act = take((size_t)rows * c.inter * es);
+    p.e = take((size_t)rows * ed * es);
+    size_t pf = 0;
+    pf = std::max(pf, gemm_part_floats(c, qkv_cols(c), c.hidden, rows));
+    pf = std::max(pf, gemm_part_floats(c, c.hidden, c.hidden, rows));
+    pf = std::max(pf, gemm_part_floats(c, gu_cols(c), c.hidden, rows));
+    pf = std::max(pf, gemm_part_floats(c, c.hidden, c.inter, rows));
+    pf = std::max(pf, gemm_part_floats(c, c.vocab, ed, rows));
+    if (ed != c.hidden) {
+        pf = std::max(pf, gemm_part_floats(c, c.hidden, ed, rows));
+        pf = std::max(pf, gemm_part_floats(c, ed, c.hidden, rows));
+    }
+    p.part_floats = pf;
+    p.part = take(pf * sizeof(float));
+    p.total = off;
+    return p;
+}
+
+extern "C" size_t sd_session_scratch_bytes(const sd_model *m, int max_rows) {
+    return plan_scratch(m->cfg, max_rows).total;
+}
+
+extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *kv_arena, void *scratch,
+                                 sd_session **out) {
+    SD_REQUIRE(m && kv_arena && scratch && out, "sd_session_create: null argument");
+    SD_REQUIRE(max_seq > 0 && max_rows > 0, "sd_session_create: bad sizes");
+    if (m->cfg.arch == SD_ARCH_OPT)
+        SD_REQUIRE(max_seq <= m->cfg.max_pos, "sd_session_create: OPT is limited to %d positions", m->cfg.max_pos);
+    else
+        SD_REQUIRE(max_seq <= m->cfg.max_pos, "sd_session_create: rope table has %d rows, max_seq %d", m->cfg.max_pos, max_seq);
+    sd_session *s = new sd_session();
+    s->m = m;
+    s->max_seq = max_seq;
+    s->max_rows = max_rows;
+    s->kv = (char *)kv_arena;
+    s->scratch = (char *)scratch;
+    const ScratchPlan p = plan_scratch(m->cfg, max_rows);
+    s->x = s->scratch + p.x;
+    s->h = s->scratch + p.h;
+    s->qbuf = s->scratch + p.q;
+    s->attn = s->scratch + p.attn;
+    s->act = s->scratch + p.act;
+    s->ebuf = s->scratch + p.e;
+    s->part = (float *)(s->scratch + p.part);
+    s->part_floats = p.part_floats;
+    s->prof_on = 0;
+    s->ev_used = 0;
+    s->prof_stream = nullptr;
+    memset(s->prof_ms, 0, sizeof(s->prof_ms));
+    memset(s->prof_cnt, 0, sizeof(s->prof_cnt));
+    *out = s;
+    return SD_OK;
+}
+
+extern "C" int sd_session_destroy(sd_session *s) {
+    if (!s) return SD_OK;
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    delete s;
+    return SD_OK;
+}
+
+// ---- profiling brackets ------------------------------------------------------------------
+struct ProfScope {
+    sd_session *s;
+    hipStream_t st;
+    bool on;
+    ProfScope(sd_session *s_, int cls, hipStream_t st_) : s(s_), st(st_), on(s_->prof_on != 0) {
+        if (!on) return;
+        while (s->ev_pool.size() < s->ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            s->ev_pool.push_back(e);
+        }
+        s->ev_class.push_back(cls);
+        (void)hipEventRecord(s->ev_pool[s->ev_used], st);
+        s->prof_stream = st;
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(s->ev_pool[s->ev_used + 1], st);
+        s->ev_used += 2;
+    }
+};
+
+extern "C" int sd_profile_enable(sd_session *s, int on) {
+    SD_REQUIRE(s, "sd_profile_enable: null session");
+    s->prof_on = on;
+    return SD_OK;
+}
+
+extern "C" int sd_profile_read(sd_session *s, float *ms_out, int *count_out) {
+    SD_REQUIRE(s && ms_out && count_out, "sd_profile_read: null argument");
+    if (s->ev_used) {
+        SD_HIP_CHECK(hipEventSynchronize(s->ev_pool[s->ev_used - 1]));
+        for (size_t i = 0; i < s->ev_used; i += 2) {
+            float ms = 0.f;
+            SD_HIP_CHECK(hipEventElapsedTime(&ms, s->ev_pool[i], s->ev_pool[i + 1]));
+            const int c = s->ev_class[i / 2];
+            s->prof_ms[c] += ms;
+            s->prof_cnt[c] += 1;
+        }
+    }
+    for (int i = 0; i < SD_N_PROFILE_CLASSES; ++i) {
+        ms_out[i] = s->prof_ms[i];
+        count_out[i] = s->prof_cnt[i];
+        s->prof_ms[i] = 0.f;
+        s->prof_cnt[i] = 0;
+    }
+    s->ev_used = 0;
+    s->ev_class.clear();
+    return SD_OK;
+}
+
+// ---- launch helpers ----------------------------------------------------------------------
+struct GemmOut {
+    int S;
+    size_t stride_s;   // floats between k-slices
+};
+
+template <int MT>
+static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
+                             int ks_per, hipStream_t st) {
+    const int units = (N / 16) * S;
+    const int blocks = (units + 3) / 4;
+    hipLaunchKernelGGL((gemm_bf16_stream<MT, 8 / (MT > 2 ? 2 : 1)>), dim3(blocks), dim3(256), 0, st,
+                       (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per);
+}
+
+// X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> part
+static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st) {
+    const sd_model_config &c = s->m->cfg;
+    ProfScope ps(s, PC_GEMM, st);
+    if (c.dtype == SD_BF16) {
+        int S, ksp;
+        gemm_split(N, K, &S, &ksp);
+        const int Mpad = (int)align_up(M, 16);
+        SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
+        const int MT = Mpad / 16;
+        if (MT == 1) launch_gemm_bf16<1>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
+        else if (MT == 2) launch_gemm_bf16<2>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
+        else if (MT <= 4) launch_gemm_bf16<4>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
+        else { sd_set_error("run_gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
+        go->S = S;
+        go->stride_s = (size_t)Mpad * N;
+    } else {
+        hipLaunchKernelGGL(gemm_f32_simple, dim3((N + 3) / 4), dim3(256), 0, st, (const float *)W, (const float *)X,
+                           s->part, M, N, K);
+        go->S = 1;
+        go->stride_s = (size_t)M * N;
+    }
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+template <typename T, int D>
+static void launch_attn(sd_session *s, const T *q, const T *k, const T *v, T *out, int n_new, int pos0,
+                        hipStream_t st) {
+    const sd_model_config &c = s->m->cfg;
+    const int s_cap = (int)align_up(pos0 + n_new, 64);
+    constexpr int NG = 256 / (D / 2);
+    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)NG * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, (n_new + ATT_TQ - 1) / ATT_TQ), dim3(256), lds, st, q, k,
+                       v, out, n_new, pos0, s->max_seq, c.n_heads, c.n_kv_heads, c.arch,
+                       1.0f / sqrtf((float)c.head_dim), s_cap);
+}
+
+template <typename T>
+static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits, float *logits_out,
+                        long ld_logits, hipStream_t st) {
+    sd_model *m = s->m;
+    const sd_model_config &c = m->cfg;
+    const int H = c.hidden, D = c.head_dim, I = c.inter, L = c.n_layers, ED = embed_dim(c);
+    const bool llama = c.arch == SD_ARCH_LLAMA;
+    const int norm_kind = llama ? NORM_RMS : NORM_LN;
+    const bool pre = llama || c.opt_pre_ln;
+    T *x = (T *)s->x, *h = (T *)s->h, *qb = (T *)s->qbuf, *at = (T *)s->attn, *ac = (T *)s->act, *eb = (T *)s->ebuf;
+    const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
+    const size_t layer_kv = (size_t)2 * c.n_kv_heads * s->max_seq * D;      // elements per layer
+    const int pos_off = 2;                                                   // OPT offset (modeling_opt.py:104)
+    GemmOut go;
+    int rc;
+
+    // ---- embeddings
+    if (llama || ED == H) {
+        ProfScope ps(s, PC_EMBED, st);
+        hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tokens, (const T *)m->w.embed, H,
+                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos0, pos_off, x);
+        SD_LAUNCH_CHECK();
+    } else {
+        {
+            ProfScope ps(s, PC_EMBED, st);
+            hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tokens, (const T *)m->w.embed, ED,
+                               (const T *)nullptr, 0, 0, eb);
+            SD_LAUNCH_CHECK();
+        }
+        if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
+        ProfScope ps(s, PC_EMBED, st);
+        hipLaunchKernelGGL((reduce_addpos_kernel<T>), dim3(n_new), dim3(256), 0, st, s->part, go.S, go.stride_s, H,
+                           (const T *)m->w.pos_embed, pos0, pos_off, x);
+        SD_LAUNCH_CHECK();
+    }
+    // ---- first pre-norm
+    if (pre) {
+        ProfScope ps(s, PC_NORM, st);
+        hipLaunchKernelGGL((norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, H, (const T *)m->n1w[0],
+                           (const T *)m->n1b[0], c.norm_eps, norm_kind, h);
+        SD_LAUNCH_CHECK();
+    } else {
+        SD_HIP_CHECK(hipMemcpyAsync(h, x, (size_t)n_new * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+    }
+
+    for (int l = 0; l < L; ++l) {
+        T *karena = (T *)s->kv + (size_t)l * layer_kv;
+        T *varena = karena + (size_t)c.n_kv_heads * s->max_seq * D;
+        // qkv projection -> rope / scale -> q buffer + in-place KV append
+        if ((rc = run_gemm(s, m->wqkv[l], h, n_new, qkv_cols(c), H, &go, st)) != SD_OK) return rc;
+        {
+            ProfScope ps(s, PC_QKV, st);
+            hipLaunchKernelGGL((qkv_epilogue_kernel<T>), dim3(n_new, c.n_heads + 2 * c.n_kv_heads),
+                               dim3(std::max(D / 2, 64)), 0, st, s->part, go.S, go.stride_s, qkv_cols(c),
+                               (const T *)m->bqkv[l], (const T *)m->w.rope_cos, (const T *)m->w.rope_sin, c.arch,
+                               1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, pos0, s->max_seq, qb, karena,
+                               varena);
+            SD_LAUNCH_CHECK();
+        }
+        {
+            ProfScope ps(s, PC_ATTN, st);
+            switch (D) {
+                case 16: launch_attn<T, 16>(s, qb, karena, varena, at, n_new, pos0, st); break;
+                case 32: launch_attn<T, 32>(s, qb, karena, varena, at, n_new, pos0, st); break;
+                case 64: launch_attn<T, 64>(s, qb, karena, varena, at, n_new, pos0, st); break;
+                default: launch_attn<T, 128>(s, qb, karena, varena, at, n_new, pos0, st); break;
+            }
+            SD_LAUNCH_CHECK();
+        }
+        // output projection + residual (+ norm feeding the MLP)
+        if ((rc = run_gemm(s, m->wo[l], at, n_new, H, H, &go, st)) != SD_OK) return rc;
+        {
+            ProfScope ps(s, PC_NORM, st);
+            const int mode = pre ? RES_PRE : RES_POST;
+            const T *nw = pre ? (const T *)m->n2w[l] : (const T *)m->n1w[l];
+            const T *nb = pre ? (const T *)m->n2b[l] : (const T *)m->n1b[l];
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, s->part, go.S,
+                               go.stride_s, H, (const T *)m->bo[l], nw, nb, c.norm_eps, norm_kind, mode, h);
+            SD_LAUNCH_CHECK();
+        }
+        // MLP
+        if ((rc = run_gemm(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
+        {
+            ProfScope ps(s, PC_ACT, st);
+            hipLaunchKernelGGL((act_kernel<T>), dim3((I + 255) / 256, n_new), dim3(256), 0, st, s->part, go.S,
+                               go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac);
+            SD_LAUNCH_CHECK();
+        }
+        if ((rc = run_gemm(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
+        {
+            ProfScope ps(s, PC_NORM, st);
+            int mode;
+            const T *nw = nullptr, *nb = nullptr;
+            if (pre) {
+                if (l + 1 < L) { mode = RES_PRE; nw = (const T *)m->n1w[l + 1]; nb = (const T *)m->n1b[l + 1]; }
+                else if (m->w.final_norm_w) { mode = RES_PRE; nw = (const T *)m->w.final_norm_w; nb = (const T *)m->w.final_norm_b; }
+                else mode = RES_NONE;
+            } else {
+                mode = RES_POST; nw = (const T *)m->n2w[l]; nb = (const T *)m->n2b[l];
+            }
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, s->part, go.S,
+                               go.stride_s, H, (const T *)m->bfc2[l], nw, nb, c.norm_eps, norm_kind, mode, h);
+            SD_LAUNCH_CHECK();
+        }
+    }
+
+    if (n_logits > 0) {
+        const T *hl = h + (size_t)(n_new - n_logits) * H;       // only the last rows are ever read
+        if (ED != H) {                                          // OPT project_out (modeling_opt.py:744-745)
+            if ((rc = run_gemm(s, m->w.project_out, hl, n_logits, ED, H, &go, st)) != SD_OK) return rc;
+            ProfScope ps(s, PC_LOGITS, st);
+            hipLaunchKernelGGL((reduce_rows_kernel<T>), dim3((ED + 255) / 256, n_logits), dim3(256), 0, st, s->part,
+                               go.S, go.stride_s, ED, eb);
+            SD_LAUNCH_CHECK();
+            hl = eb;
+        }
+        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st)) != SD_OK) return rc;
+        ProfScope ps(s, PC_LOGITS, st);
+        hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
+                           go.stride_s, c.vocab, c.logits_bf16_round || (!llama && c.dtype == SD_BF16), logits_out,
+                           ld_logits);
+        SD_LAUNCH_CHECK();
+    }
+    return SD_OK;
+}
+
+extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
+                                  float *logits_out, long ld_logits, void *stream) {
+    SD_REQUIRE(s && tokens, "sd_session_forward: null argument");
+    SD_REQUIRE(n_new >= 1 && pos0 >= 0, "sd_session_forward: n_new=%d pos0=%d", n_new, pos0);
+    SD_REQUIRE(n_logits >= 0 && n_logits <= n_new, "sd_session_forward: n_logits=%d of n_new=%d", n_logits, n_new);
+    SD_REQUIRE(n_logits == 0 || logits_out, "sd_session_forward: logits_out is null");
+    if (n_new > s->max_rows || n_new > 64 || pos0 + n_new > s->max_seq) {
+        sd_set_error("sd_session_forward: n_new=%d (max_rows %d, <=64), pos0+n_new=%d (max_seq %d)", n_new,
+                     s->max_rows, pos0 + n_new, s->max_seq);
+        return SD_ERR_CAPACITY;
+    }
+    if (s->m->cfg.dtype == SD_BF16)
+        return forward_impl<bf16_t>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
+    return forward_impl<float>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
+}

@@ -1,0 +1,440 @@
+// Decoder-forward kernels for gfx950 (Llama / OPT, fp32 or bf16 storage).
+// Reference semantics: sampling/models/modeling_llama.py:292-393, 405-457 and
+// sampling/models/modeling_opt.py:160-278, 303-378; every rnd<T>() marks a point where the
+// reference's per-op result is materialised in the weight dtype.
+#pragma once
+#include "common.h"
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+enum { NORM_RMS = 0, NORM_LN = 1 };
+enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual feeds the next GEMM / replaces x / no norm
+
+// ------------------------------------------------------------------------------------------
+// Weight-streaming GEMM  part[s][m][n] = sum_{k in slice s} X[m][k] * W[n][k]
+// bf16: W in 1 KiB tiles [N/16][K/32][64 lanes][8], one wave = one (n-tile, k-slice) unit.
+// The MFMA runs with A = W tile (rows n), B = X^T (cols m): lane holds D[n = 4*(lane>>4)+j][m = lane&15],
+// so each lane stores 4 consecutive n as one float4.
+// ------------------------------------------------------------------------------------------
+template <int MT, int UNROLL>
+__global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
+                                                       float *__restrict__ part, int M, int Mpad, int N, int K,
+                                                       int S, int ks_per) {
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int NTL = N >> 4, KS = K >> 5;
+    if (unit >= NTL * S) return;
+    const int s = unit / NTL, nt = unit - s * NTL;
+    const int ks0 = s * ks_per, ks1 = min(KS, ks0 + ks_per);
+    const u32x4 *wp = Wp + ((size_t)nt * KS + ks0) * 64 + lane;
+    const int mrow = lane & 15, kq = (lane >> 4) * 8;
+    const bf16_t *xp[MT];
+    bool mv[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = t * 16 + mrow;
+        mv[t] = m < M;
+        xp[t] = X + (size_t)(mv[t] ? m : 0) * K + (size_t)ks0 * 32 + kq;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ks = ks0;
+    for (; ks + UNROLL <= ks1; ks += UNROLL) {
+        u32x4 w[UNROLL];
+        u32x4 x[UNROLL][MT];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * 32) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u]),
+                                                                __builtin_bit_cast(bf16x8, x[u][t]), acc[t], 0, 0, 0);
+        wp += (size_t)UNROLL * 64;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xp[t] += UNROLL * 32;
+    }
+    for (; ks < ks1; ++ks) {
+        const u32x4 w = __builtin_nontemporal_load(wp);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const u32x4 x = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t]) : u32x4{0u, 0u, 0u, 0u};
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
+                                                            __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+            xp[t] += 32;
+        }
+        wp += 64;
+    }
+    const int n = nt * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+        if (mv[t])
+            *reinterpret_cast<f32x4 *>(part + ((size_t)s * Mpad + t * 16 + mrow) * N + n) = acc[t];
+}
+
+// fp32 storage (parity runs on small models): one wave per output column, lanes stride K.
+__global__ __launch_bounds__(256) void gemm_f32_simple(const float *__restrict__ W, const float *__restrict__ X,
+                                                      float *__restrict__ part, int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *w = W + (size_t)n * K;
+    for (int m = 0; m < M; ++m) {
+        const float *x = X + (size_t)m * K;
+        float a = 0.f;
+        for (int k = lane; k < K; k += 64) a = fmaf(w[k], x[k], a);
+        a = wave_sum(a);
+        if (lane == 0) part[(size_t)m * N + n] = a;
+    }
+}
+
+// bf16 [N][K] row-major -> streaming tiles (see sd_pack_weight_bf16 in specdec.h)
+__global__ void pack_weight_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int N, int K) {
+    const size_t total = (size_t)N * K / 8;                       // one thread moves 8 contiguous bf16
+    const int KS = K >> 5;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(g & 63);
+        const size_t tile = g >> 6;
+        const int ks = (int)(tile % KS), nt = (int)(tile / KS);
+        const int n = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8;
+        *reinterpret_cast<uint4 *>(dst + g * 8) = *reinterpret_cast<const uint4 *>(src + (size_t)n * K + k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K reduction of one (row, col) element, with the Linear's bias and output rounding
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float reduce_part(const float *__restrict__ part, int S, size_t stride_s, size_t off,
+                                             const T *__restrict__ bias, int col) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * stride_s + off];
+    if (bias) a += to_f(bias[col]);
+    return rnd<T>(a);
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding gather (+ OPT learned positions when there is no project_in)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const int32_t *__restrict__ tokens, const T *__restrict__ table, int dim,
+                             const T *__restrict__ pos_table, int pos0, int pos_off, T *__restrict__ out) {
+    const int row = blockIdx.x;
+    const int tok = tokens[row];
+    const T *src = table + (size_t)tok * dim;
+    const T *ps = pos_table ? pos_table + (size_t)(pos0 + row + pos_off) * dim : nullptr;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        float v = to_f(src[i]);
+        if (ps) v = rnd<T>(v + to_f(ps[i]));
+        out[(size_t)row * dim + i] = from_f<T>(v);
+    }
+}
+
+// x = rnd(rnd(sum part) + pos)   (OPT project_in output plus learned positions, modeling_opt.py:669-672)
+template <typename T>
+__global__ void reduce_addpos_kernel(const float *__restrict__ part, int S, size_t stride_s, int N,
+                                     const T *__restrict__ pos_table, int pos0, int pos_off, T *__restrict__ out) {
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        float v = reduce_part<T>(part, S, stride_s, (size_t)row * N + i, nullptr, i);
+        if (pos_table) v = rnd<T>(v + to_f(pos_table[(size_t)(pos0 + row + pos_off) * N + i]));
+        out[(size_t)row * N + i] = from_f<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Norms.  RMS: modeling_llama.py:84-89 (fp32 statistics, cast, weight multiply in T).
+// LayerNorm: nn.LayerNorm (fp32 math, one rounding at the end).
+// The row lives in LDS (H floats) between the two passes.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, const T *__restrict__ w,
+                                         const T *__restrict__ b, float eps, int kind, float *red,
+                                         T *__restrict__ dst0, T *__restrict__ dst1) {
+    float a = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float v = xs[i];
+        a += v;
+        a2 += v * v;
+    }
+    if (kind == NORM_RMS) {
+        const float var = block_sum(a2, red) / (float)H;
+        const float r = rsqrtf(var + eps);
+        for (int i = threadIdx.x; i < H; i += blockDim.x) {
+            const float y = rnd<T>(to_f(w[i]) * rnd<T>(xs[i] * r));
+            if (dst0) dst0[i] = from_f<T>(y);
+            if (dst1) dst1[i] = from_f<T>(y);
+        }
+    } else {
+        const float mean = block_sum(a, red) / (float)H;
+        float d2 = 0.f;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) {
+            const float d = xs[i] - mean;
+            d2 += d * d;
+        }
+        const float var = block_sum(d2, red) / (float)H;
+        const float r = 1.0f / sqrtf(var + eps);
+        for (int i = threadIdx.x; i < H; i += blockDim.x) {
+            const float y = rnd<T>((xs[i] - mean) * r * to_f(w[i]) + to_f(b[i]));
+            if (dst0) dst0[i] = from_f<T>(y);
+            if (dst1) dst1[i] = from_f<T>(y);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_kernel(const T *__restrict__ x, int H, const T *__restrict__ w,
+                                                  const T *__restrict__ b, float eps, int kind,
+                                                  T *__restrict__ h) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    float *red = xs + H;
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) xs[i] = to_f(x[(size_t)row * H + i]);
+    __syncthreads();
+    norm_row<T>(xs, H, w, b, eps, kind, red, h + (size_t)row * H, nullptr);
+}
+
+// x' = rnd(x + rnd(sum part + bias)); then per mode: PRE: x <- x', h <- norm(x');  POST: x,h <- LN(x');
+// NONE: x,h <- x'.   (residual adds: modeling_llama.py:440,446; modeling_opt.py:342-347, 363-368)
+template <typename T>
+__global__ __launch_bounds__(256) void residual_norm_kernel(T *__restrict__ x, const float *__restrict__ part, int S,
+                                                           size_t stride_s, int H, const T *__restrict__ bias,
+                                                           const T *__restrict__ w, const T *__restrict__ b,
+                                                           float eps, int kind, int mode, T *__restrict__ h) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    float *red = xs + H;
+    const int row = blockIdx.x;
+    T *xr = x + (size_t)row * H;
+    T *hr = h + (size_t)row * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float y = reduce_part<T>(part, S, stride_s, (size_t)row * H + i, bias, i);
+        const float v = rnd<T>(to_f(xr[i]) + y);
+        xs[i] = v;
+        if (mode != RES_POST) xr[i] = from_f<T>(v);
+        if (mode == RES_NONE) hr[i] = from_f<T>(v);
+    }
+    __syncthreads();
+    if (mode == RES_PRE) norm_row<T>(xs, H, w, b, eps, kind, red, hr, nullptr);
+    else if (mode == RES_POST) norm_row<T>(xs, H, w, b, eps, kind, red, hr, xr);
+}
+
+// ------------------------------------------------------------------------------------------
+// QKV epilogue: split-K reduce, bias, RoPE (llama) / q pre-scale (OPT), K/V appended in place
+// into the arena rows pos0..pos0+n_new-1 (replaces torch.cat, modeling_llama.py:337-338).
+// grid (n_new, Hq + 2*Hkv), D/2 threads.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_t stride_s, int Nqkv,
+                                    const T *__restrict__ bias, const T *__restrict__ cos_t,
+                                    const T *__restrict__ sin_t, int arch, float q_scale, int Hq, int Hkv, int D,
+                                    int pos0, int max_seq, T *__restrict__ qbuf, T *__restrict__ karena,
+                                    T *__restrict__ varena) {
+    const int row = blockIdx.x, head = blockIdx.y, d = threadIdx.x, hd = D >> 1;
+    if (d >= hd) return;
+    const int col0 = head * D + d, col1 = col0 + hd;
+    const float v0 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col0, bias, col0);
+    const float v1 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col1, bias, col1);
+    float o0 = v0, o1 = v1;
+    const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
+    if (arch == SD_ARCH_LLAMA && (is_q || is_k)) {
+        const float c = to_f(cos_t[(size_t)(pos0 + row) * hd + d]);
+        const float s = to_f(sin_t[(size_t)(pos0 + row) * hd + d]);
+        // q*cos + rotate_half(q)*sin with rotate_half = cat(-x2, x1)   (modeling_llama.py:173-188)
+        o0 = rnd<T>(rnd<T>(v0 * c) + rnd<T>(-v1 * s));
+        o1 = rnd<T>(rnd<T>(v1 * c) + rnd<T>(v0 * s));
+    } else if (arch == SD_ARCH_OPT && is_q) {
+        o0 = rnd<T>(v0 * q_scale);                                // modeling_opt.py:178
+        o1 = rnd<T>(v1 * q_scale);
+    }
+    if (is_q) {
+        T *q = qbuf + (size_t)row * Hq * D + head * D;
+        q[d] = from_f<T>(o0);
+        q[d + hd] = from_f<T>(o1);
+    } else {
+        const int kvh = is_k ? head - Hq : head - Hq - Hkv;
+        T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + pos0 + row) * D;
+        dst[d] = from_f<T>(o0);
+        dst[d + hd] = from_f<T>(o1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention of <= TQ new query rows of one head against the arena (causal).
+// Phase 1: one thread per key (its D contiguous elements, 16-byte loads), q rows broadcast from LDS.
+// Phase 2: fp32 softmax per row.  Phase 3: P.V with (D/2) lanes across the head dim, keys striped
+// over the remaining thread groups, reduced through LDS.
+// ------------------------------------------------------------------------------------------
+
+// 8 consecutive storage elements -> fp32 (one 16-byte load for bf16, two for fp32)
+__device__ __forceinline__ void load8(const bf16_t *p, float (&o)[8]) {
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(v[i] << 16);
+        o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+#define ATT_TQ 8
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, const T *__restrict__ karena,
+                                                  const T *__restrict__ varena, T *__restrict__ out, int n_new,
+                                                  int pos0, int max_seq, int Hq, int Hkv, int arch,
+                                                  float inv_sqrt_d, int s_cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
+    float *red = qs + ATT_TQ * D;                                 // [NG][TQ][D]
+    constexpr int HD = D / 2, NG = 256 / HD;
+    float *sc = red + NG * ATT_TQ * D;                            // [TQ][s_cap]
+    const int head = blockIdx.x, r0 = blockIdx.y * ATT_TQ;
+    const int nr = min(ATT_TQ, n_new - r0);
+    const int kvh = head / (Hq / Hkv);
+    const T *K = karena + (size_t)kvh * max_seq * D;
+    const T *Vv = varena + (size_t)kvh * max_seq * D;
+    const int tid = threadIdx.x;
+    const int s_hi = pos0 + r0 + nr;                              // keys visible to the last row of the group
+
+    for (int i = tid; i < ATT_TQ * D; i += 256) {
+        const int t = i / D, d = i - t * D;
+        qs[i] = t < nr ? to_f(qbuf[(size_t)(r0 + t) * Hq * D + head * D + d]) : 0.f;
+    }
+    __syncthreads();
+
+    for (int s = tid; s < s_hi; s += 256) {
+        float acc[ATT_TQ];
+#pragma unroll
+        for (int t = 0; t < ATT_TQ; ++t) acc[t] = 0.f;
+        const T *kr = K + (size_t)s * D;
+#pragma unroll 2
+        for (int d = 0; d < D; d += 8) {
+            float kv[8];
+            load8(kr + d, kv);
+#pragma unroll
+            for (int t = 0; t < ATT_TQ; ++t) {
+                const float4 qa = *reinterpret_cast<const float4 *>(qs + t * D + d);
+                const float4 qb = *reinterpret_cast<const float4 *>(qs + t * D + d + 4);
+                acc[t] = fmaf(kv[0], qa.x, acc[t]);
+                acc[t] = fmaf(kv[1], qa.y, acc[t]);
+                acc[t] = fmaf(kv[2], qa.z, acc[t]);
+                acc[t] = fmaf(kv[3], qa.w, acc[t]);
+                acc[t] = fmaf(kv[4], qb.x, acc[t]);
+                acc[t] = fmaf(kv[5], qb.y, acc[t]);
+                acc[t] = fmaf(kv[6], qb.z, acc[t]);
+                acc[t] = fmaf(kv[7], qb.w, acc[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < ATT_TQ; ++t) {
+            float v = rnd<T>(acc[t]);                             // matmul result in T
+            if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d) ;  // scale after the matmul (modeling_llama.py:346)
+            sc[(size_t)t * s_cap + s] = (s <= pos0 + r0 + t) ? v : -INFINITY;
+        }
+    }
+    __syncthreads();
+
+    {   // softmax in fp32, result rounded to T (modeling_llama.py:371)
+        const int w = tid >> 6, lane = tid & 63;
+        for (int t = w; t < nr; t += 4) {
+            float *row = sc + (size_t)t * s_cap;
+            const int len = pos0 + r0 + t + 1;
+            float m = -INFINITY;
+            for (int s = lane; s < len; s += 64) m = fmaxf(m, row[s]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int s = lane; s < len; s += 64) {
+                const float e = expf(row[s] - m);
+                row[s] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? rnd<T>(row[s] / sum) : 0.f;
+        }
+    }
+    __syncthreads();
+
+    {
+        const int dp = tid % HD, sg = tid / HD;
+        float a0[ATT_TQ], a1[ATT_TQ];
+#pragma unroll
+        for (int t = 0; t < ATT_TQ; ++t) a0[t] = a1[t] = 0.f;
+        for (int s = sg; s < s_hi; s += NG) {
+            const float v0 = to_f(Vv[(size_t)s * D + 2 * dp]), v1 = to_f(Vv[(size_t)s * D + 2 * dp + 1]);
+#pragma unroll
+            for (int t = 0; t < ATT_TQ; ++t) {
+                const float p = sc[(size_t)t * s_cap + s];
+                a0[t] = fmaf(p, v0, a0[t]);
+                a1[t] = fmaf(p, v1, a1[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < ATT_TQ; ++t) {
+            red[((size_t)sg * ATT_TQ + t) * D + 2 * dp] = a0[t];
+            red[((size_t)sg * ATT_TQ + t) * D + 2 * dp + 1] = a1[t];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * D; i += 256) {
+        const int t = i / D, d = i - t * D;
+        float a = 0.f;
+        for (int g = 0; g < NG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+        out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MLP activation epilogue.  llama: silu(gate) * up (modeling_llama.py:220); OPT: relu(fc1 + b).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void act_kernel(const float *__restrict__ part, int S, size_t stride_s, int I, int Ncols, int arch,
+                           const T *__restrict__ bias, T *__restrict__ act) {
+    const int row = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= I) return;
+    float a;
+    if (arch == SD_ARCH_LLAMA) {
+        const float g = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + c, nullptr, c);
+        const float u = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + I + c, nullptr, c);
+        const float sg = rnd<T>(g / (1.0f + expf(-g)));
+        a = rnd<T>(sg * u);
+    } else {
+        const float f = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + c, bias, c);
+        a = f > 0.f ? f : 0.f;
+    }
+    act[(size_t)row * I + c] = from_f<T>(a);
+}
+
+// Generic split-K reduce into T rows (OPT project_out) or fp32 logits.
+template <typename T>
+__global__ void reduce_rows_kernel(const float *__restrict__ part, int S, size_t stride_s, int N,
+                                   T *__restrict__ out) {
+    const int row = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    out[(size_t)row * N + c] = from_f<T>(reduce_part<T>(part, S, stride_s, (size_t)row * N + c, nullptr, c));
+}
+
+template <typename T>
+__global__ void logits_kernel(const float *__restrict__ part, int S, size_t stride_s, int V, int round_t,
+                              float *__restrict__ out, long ld) {
+    const int row = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= V) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += part[(size_t)s * stride_s + (size_t)row * V + c];
+    if (round_t) a = rnd<T>(a);
+    out[(size_t)row * ld + c] = a;
+}

@@ -1,0 +1,294 @@
+"""Device-resident decoder models and sessions on top of libspecdec.so.
+
+``SpecDecModel`` holds one model's weights in HBM in the layout the HIP kernels
+stream (bf16 GEMM matrices tile-packed) plus the ``sd_model`` handle.
+``Session`` is one sequence's KV arena + scratch: the state a reference
+``KVCacheModel`` keeps in ``_past_key_values`` (kvcache_model.py:24-36).
+
+PyTorch is used here for device memory, streams and weight loading only; every
+kernel on the path is in csrc/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .config import ModelConfig, config_from_hf
+
+MAX_ROWS_PER_FORWARD = 64       # one sd_session_forward call; longer prompts are chunked
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class SpecDecModel:
+    """Weights in HBM + sd_model handle.  Exposes what the reference reads off a model object:
+    ``.config.is_encoder_decoder`` (speculative_sampling.py:1942) and ``.device`` (:1909)."""
+
+    def __init__(self, cfg: ModelConfig, get_tensor: Callable[[str], torch.Tensor],
+                 dtype: torch.dtype = torch.bfloat16, device: str = "cuda", max_pos: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SpecDecModel needs a GPU: the HIP path has no CPU fallback")
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.config = cfg
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.max_pos = int(max_pos or cfg.max_position_embeddings)
+        self._keep: List[torch.Tensor] = []          # owns every device tensor the handle points into
+        self._arrays = []
+        self.weight_bytes = 0                        # bytes the forward streams (embedding tables excluded)
+        self._build(get_tensor)
+
+    # -- weight staging ---------------------------------------------------------------------
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _gemm_weight(self, t: torch.Tensor) -> torch.Tensor:
+        """[N][K] matrix -> device layout for the GEMM kernels."""
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        self.weight_bytes += t.numel() * t.element_size()
+        if self.dtype == torch.bfloat16:
+            N, K = t.shape
+            out = torch.empty_like(t)
+            check(lib.sd_pack_weight_bf16(t.data_ptr(), out.data_ptr(), N, K, _stream()), "sd_pack_weight_bf16")
+            torch.cuda.current_stream().synchronize()
+            t = out
+        self._keep.append(t)
+        return t
+
+    def _ptr_array(self, tensors: List[Optional[torch.Tensor]]):
+        arr = (C.c_void_p * len(tensors))(*[_ptr(t) for t in tensors])
+        self._arrays.append(arr)
+        return C.cast(arr, C.POINTER(C.c_void_p))
+
+    def _build(self, get: Callable[[str], torch.Tensor]):
+        cfg = self.cfg
+        L = cfg.num_hidden_layers
+        w = _lib.SdModelWeights()
+        wqkv, bqkv, wo, bo, wgu, bfc1, wdn, bfc2, n1w, n1b, n2w, n2b = ([] for _ in range(12))
+        with torch.no_grad():
+            if cfg.arch == "llama":
+                w.embed = _ptr(self._dev(get("model.embed_tokens.weight")))
+                for i in range(L):
+                    p = f"model.layers.{i}."
+                    q, k, v = (get(p + f"self_attn.{n}_proj.weight") for n in "qkv")
+                    wqkv.append(self._gemm_weight(torch.cat([q.to(self.device), k.to(self.device), v.to(self.device)], 0)))
+                    del q, k, v
+                    wo.append(self._gemm_weight(get(p + "self_attn.o_proj.weight")))
+                    g, u = get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")
+                    wgu.append(self._gemm_weight(torch.cat([g.to(self.device), u.to(self.device)], 0)))
+                    del g, u
+                    wdn.append(self._gemm_weight(get(p + "mlp.down_proj.weight")))
+                    n1w.append(self._dev(get(p + "input_layernorm.weight")))
+                    n2w.append(self._dev(get(p + "post_attention_layernorm.weight")))
+                    for lst in (bqkv, bo, bfc1, bfc2, n1b, n2b):
+                        lst.append(None)
+                w.final_norm_w = _ptr(self._dev(get("model.norm.weight")))
+                w.lm_head = _ptr(self._gemm_weight(get("lm_head.weight")))
+                # rope table exactly as the reference builds it (modeling_llama.py:107-125)
+                D = cfg.head_dim
+                inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2).float() / D))
+                ang = torch.outer(torch.arange(self.max_pos, dtype=torch.float32), inv)
+                w.rope_cos = _ptr(self._dev(ang.cos()))
+                w.rope_sin = _ptr(self._dev(ang.sin()))
+                self.weight_bytes += (2 * L + 1) * cfg.hidden_size * (2 if self.dtype == torch.bfloat16 else 4)
+            else:
+                d = "model.decoder."
+                emb = get(d + "embed_tokens.weight")
+                w.embed = _ptr(self._dev(emb))
+                w.lm_head = _ptr(self._gemm_weight(emb))          # tied head (modeling_opt.py:833,840)
+                del emb
+                w.pos_embed = _ptr(self._dev(get(d + "embed_positions.weight")))
+                if cfg.word_embed_proj_dim != cfg.hidden_size:
+                    w.project_in = _ptr(self._gemm_weight(get(d + "project_in.weight")))
+                    w.project_out = _ptr(self._gemm_weight(get(d + "project_out.weight")))
+                if cfg.do_layer_norm_before:
+                    w.final_norm_w = _ptr(self._dev(get(d + "final_layer_norm.weight")))
+                    w.final_norm_b = _ptr(self._dev(get(d + "final_layer_norm.bias")))
+                for i in range(L):
+                    p = d + f"layers.{i}."
+                    q, k, v = (get(p + f"self_attn.{n}_proj.weight") for n in "qkv")
+                    wqkv.append(self._gemm_weight(torch.cat([q.to(self.device), k.to(self.device), v.to(self.device)], 0)))
+                    bqkv.append(self._dev(torch.cat([get(p + f"self_attn.{n}_proj.bias").to(self.device) for n in "qkv"], 0)))
+                    wo.append(self._gemm_weight(get(p + "self_attn.out_proj.weight")))
+                    bo.append(self._dev(get(p + "self_attn.out_proj.bias")))
+                    wgu.append(self._gemm_weight(get(p + "fc1.weight")))
+                    bfc1.append(self._dev(get(p + "fc1.bias")))
+                    wdn.append(self._gemm_weight(get(p + "fc2.weight")))
+                    bfc2.append(self._dev(get(p + "fc2.bias")))
+                    n1w.append(self._dev(get(p + "self_attn_layer_norm.weight")))
+                    n1b.append(self._dev(get(p + "self_attn_layer_norm.bias")))
+                    n2w.append(self._dev(get(p + "final_layer_norm.weight")))
+                    n2b.append(self._dev(get(p + "final_layer_norm.bias")))
+        w.wqkv, w.bqkv = self._ptr_array(wqkv), self._ptr_array(bqkv)
+        w.wo, w.bo = self._ptr_array(wo), self._ptr_array(bo)
+        w.w_gate_up, w.b_fc1 = self._ptr_array(wgu), self._ptr_array(bfc1)
+        w.w_down, w.b_fc2 = self._ptr_array(wdn), self._ptr_array(bfc2)
+        w.norm1_w, w.norm1_b = self._ptr_array(n1w), self._ptr_array(n1b)
+        w.norm2_w, w.norm2_b = self._ptr_array(n2w), self._ptr_array(n2b)
+
+        c = _lib.SdModelConfig(
+            arch=cfg.arch_id, dtype=_lib.SD_BF16 if self.dtype == torch.bfloat16 else _lib.SD_F32,
+            vocab=cfg.vocab_size, hidden=cfg.hidden_size, inter=cfg.intermediate_size, n_layers=L,
+            n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+            max_pos=self.max_pos, opt_pre_ln=int(cfg.do_layer_norm_before), opt_proj_dim=cfg.word_embed_proj_dim or cfg.hidden_size,
+            norm_eps=cfg.rms_norm_eps if cfg.arch == "llama" else cfg.layer_norm_eps,
+            logits_bf16_round=int(self.dtype == torch.bfloat16))
+        h = C.c_void_p()
+        check(lib.sd_model_create(C.byref(c), C.byref(w), C.byref(h)), "sd_model_create")
+        self.handle = h
+        self._w, self._c = w, c
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            lib.sd_model_destroy(h)
+            self.handle = None
+
+    # -- constructors -----------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, cfg: ModelConfig, sd: Dict[str, torch.Tensor], dtype=torch.bfloat16,
+                        device="cuda", max_pos=None) -> "SpecDecModel":
+        return cls(cfg, lambda n: sd[n], dtype=dtype, device=device, max_pos=max_pos)
+
+    @classmethod
+    def from_hf(cls, module, dtype: Optional[torch.dtype] = None, device="cuda", max_pos=None) -> "SpecDecModel":
+        """Extract weights from a transformers LlamaForCausalLM / OPTForCausalLM (reference
+        evaluation.py:183-253 hands such modules to speculative_sampling)."""
+        cfg = config_from_hf(module.config)
+        sd = module.state_dict()
+        if dtype is None:
+            dtype = torch.bfloat16 if next(iter(sd.values())).dtype != torch.float32 else torch.float32
+        return cls(cfg, lambda n: sd[n], dtype=dtype, device=device, max_pos=max_pos)
+
+    @classmethod
+    def synthetic(cls, cfg: ModelConfig, seed: int, dtype=torch.bfloat16, device="cuda", max_pos=None,
+                  method: str = "torch", gain: float = 1.0, head_gain: float = 4.0) -> "SpecDecModel":
+        """Random-init weights generated tensor by tensor (never the whole model at once on the host)."""
+        from .synth import param_shapes, _scale
+        import numpy as np
+        shapes = {n: (i, s, k) for i, (n, s, k) in enumerate(param_shapes(cfg))}
+        gen = torch.Generator(device=device)
+
+        def get(name: str) -> torch.Tensor:
+            idx, shape, kind = shapes[name]
+            mean, std = _scale(kind, shape, gain, head_gain)
+            if method == "numpy":
+                rng = np.random.default_rng([int(seed), idx])
+                a = rng.standard_normal(size=shape, dtype=np.float32) * np.float32(std) + np.float32(mean)
+                return torch.from_numpy(a)
+            gen.manual_seed(int(seed) * 100003 + idx)
+            t = torch.empty(shape, dtype=torch.float32 if dtype == torch.float32 else torch.bfloat16, device=device)
+            return t.normal_(mean, std, generator=gen)
+        return cls(cfg, get, dtype=dtype, device=device, max_pos=max_pos)
+
+    def export_state_dict(self) -> Dict[str, torch.Tensor]:
+        raise NotImplementedError
+
+    def new_session(self, max_seq: int, max_rows: int = MAX_ROWS_PER_FORWARD) -> "Session":
+        return Session(self, max_seq, max_rows)
+
+
+class Session:
+    """KV arena [L][2][H_kv][max_seq][D] + scratch for one sequence; ``cache_len`` is the number of
+    positions held, so rollback is an assignment (reference kvcache_model.py:359-436)."""
+
+    def __init__(self, model: SpecDecModel, max_seq: int, max_rows: int = MAX_ROWS_PER_FORWARD):
+        cfg = model.cfg
+        self.model = model
+        self.max_seq = int(min(max_seq, model.max_pos))
+        self.max_rows = int(min(max_rows, MAX_ROWS_PER_FORWARD))
+        dev = model.device
+        self.kv = torch.zeros((cfg.num_hidden_layers, 2, cfg.num_key_value_heads, self.max_seq, cfg.head_dim),
+                              dtype=model.dtype, device=dev)
+        assert self.kv.numel() * self.kv.element_size() == lib.sd_session_kv_bytes(model.handle, self.max_seq)
+        nbytes = lib.sd_session_scratch_bytes(model.handle, self.max_rows)
+        self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.logits = torch.empty((self.max_rows, cfg.vocab_size), dtype=torch.float32, device=dev)
+        h = C.c_void_p()
+        check(lib.sd_session_create(model.handle, self.max_seq, self.max_rows, self.kv.data_ptr(),
+                                    self.scratch.data_ptr(), C.byref(h)), "sd_session_create")
+        self.handle = h
+        self.cache_len = 0
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            lib.sd_session_destroy(h)
+            self.handle = None
+
+    def forward(self, tokens: torch.Tensor, n_logits: int, logits_out: Optional[torch.Tensor] = None,
+                pos0: Optional[int] = None) -> torch.Tensor:
+        """Feed ``tokens`` (device int32, 1-D) at positions pos0.. (default: append at cache_len); returns
+        fp32 logits of the last ``n_logits`` fed rows (a view of ``logits_out`` or of the session buffer).
+        Prompts longer than one launch chain's row budget are chunked."""
+        assert tokens.dtype == torch.int32 and tokens.is_cuda and tokens.dim() == 1
+        n = tokens.numel()
+        if pos0 is None:
+            pos0 = self.cache_len
+        if logits_out is None:
+            logits_out = self.logits
+        assert n_logits <= logits_out.shape[0] and logits_out.stride(1) == 1
+        ld = logits_out.stride(0)
+        st = _stream()
+        first_logit_row = n - n_logits
+        done = 0
+        while done < n:
+            m = min(self.max_rows, n - done)
+            lo = max(first_logit_row, done)            # rows of this chunk that need logits
+            nl = max(0, done + m - lo)
+            dst = logits_out.data_ptr() + (lo - first_logit_row) * ld * 4 if nl else None
+            check(lib.sd_session_forward(self.handle, tokens.data_ptr() + done * 4, m, pos0 + done, nl, dst, ld, st),
+                  "sd_session_forward")
+            done += m
+        self.cache_len = pos0 + n
+        return logits_out[:n_logits]
+
+    def rollback(self, end_pos: int) -> None:
+        self.cache_len = min(self.cache_len, int(end_pos))
+
+    def past_key_values(self):
+        """The reference's tuple layout: one (k, v) pair of (1, H_kv, S, D) views per layer."""
+        S = self.cache_len
+        return [(self.kv[l, 0, :, :S, :].unsqueeze(0), self.kv[l, 1, :, :S, :].unsqueeze(0))
+                for l in range(self.kv.shape[0])]
+
+    # -- per-op-class timing (roofline report) ----------------------------------------------
+    def profile(self, on: bool) -> None:
+        check(lib.sd_profile_enable(self.handle, int(on)), "sd_profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_float * _lib.N_PROFILE_CLASSES)()
+        cnt = (C.c_int * _lib.N_PROFILE_CLASSES)()
+        check(lib.sd_profile_read(self.handle, ms, cnt), "sd_profile_read")
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(_lib.PROFILE_CLASS_NAMES) if cnt[i]}
+
+
+_MODEL_CACHE: Dict[int, SpecDecModel] = {}
+
+
+def as_specdec_model(model, dtype: Optional[torch.dtype] = None) -> SpecDecModel:
+    """Accept the engine's own model or an HF module (converted once, cached by id)."""
+    if isinstance(model, SpecDecModel):
+        return model
+    key = id(model)
+    if key not in _MODEL_CACHE:
+        if not hasattr(model, "state_dict") or not hasattr(model, "config"):
+            raise TypeError(f"cannot use {type(model).__name__} as a decoder model")
+        if getattr(model.config, "is_encoder_decoder", False):
+            raise NotImplementedError("encoder-decoder models (reference speculative_sampling.py:1946,1958) are out of scope")
+        _MODEL_CACHE[key] = SpecDecModel.from_hf(model, dtype=dtype)
+    return _MODEL_CACHE[key]

@@ -1,0 +1,346 @@
+"""Parity of the HIP path (through the C ABI) against the reference's golden vectors and the oracle.
+
+Run with ``pytest -m gpu`` on an MI355X.  Bars: token ids bit-exact; probabilities within 1e-6
+absolute with an identical support set; fp32 logits within 1e-3 (north_star); bf16 logits within
+0.25 of the reference's bf16 forward (same bar the oracle is held to).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_io import DT, dense_from_sparse, events, load, logits_row, model_pair
+from llmspeculativesampling_amd.config import load_config
+from llmspeculativesampling_amd.synth import make_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import llmspeculativesampling_amd.sampling as S
+    from llmspeculativesampling_amd import _lib, engine, noise
+    import types
+    return types.SimpleNamespace(S=S, lib=_lib.lib, L=_lib, engine=engine, noise=noise)
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- G1 norm_probs
+G1_META, G1 = load("g1_norm_logits")
+G1_F32 = [c for c in G1_META if c.get("dtype", "float32") == "float32"]
+
+
+@pytest.mark.parametrize("case", G1_F32, ids=[c["id"] for c in G1_F32])
+def test_norm_probs_golden(hip, case):
+    if case["kind"] == "error":
+        row = torch.tensor([[float(v) for v in case["row"]]], device="cuda")
+        with pytest.raises(RuntimeError, match="norm logits error"):
+            hip.S.norm_logits(row, case["T"], case["k"], case["p"])
+        return
+    if case["kind"] == "inline":
+        x = torch.tensor([[float(v) for v in case["row"]]], dtype=torch.float32)
+        want = np.array(case["expect"], dtype=np.float32)
+    else:
+        x = logits_row(case["seed"], case["V"], case["scale"])
+        want = G1[case["id"] + "_dense"] if case["dense"] else dense_from_sparse(
+            case["V"], G1[case["id"] + "_idx"], G1[case["id"] + "_val"])
+    got = hip.S.norm_logits(x.cuda(), case["T"], case["k"], case["p"]).cpu().numpy()[0]
+    np.testing.assert_array_equal(got > 0, want > 0)            # identical support set
+    np.testing.assert_allclose(got, want, atol=1e-6, rtol=0)
+
+
+def test_norm_probs_many_rows_vs_oracle(hip):
+    """Random rows, several (T,k,p) incl. the general top-p path (no top-k) at V = 32000 / 50272."""
+    for V in (1000, 32000, 50272):
+        for (T, k, p) in [(1.0, 20, 0.9), (0.8, 0, 0.9), (1.0, 0, 0.0), (1.0, 2000, 0.99), (1.0, 50, 0.0)]:
+            rows = torch.cat([logits_row(4242 + i, V, 3.0) for i in range(3)], 0)
+            got = hip.S.norm_logits(rows.cuda(), T, k, p).cpu()
+            for i in range(rows.shape[0]):
+                want = oracle.norm_logits(rows[i:i + 1], T, k, p)[0]
+                assert torch.equal(got[i] > 0, want > 0), (V, T, k, p, i)
+                assert float((got[i] - want).abs().max()) <= 1e-6
+
+
+# --------------------------------------------------------------------------- G2 sample / G3 max_fn
+G2_META, G2 = load("g2_sample")
+
+
+@pytest.mark.parametrize("case", G2_META["sample"], ids=[c["id"] for c in G2_META["sample"]])
+def test_sample_golden(hip, case):
+    if case["id"] == "allzero_raises":
+        st = torch.get_rng_state()
+        with pytest.raises(RuntimeError, match="prob error"):
+            hip.S.sample(torch.zeros(1, case["V"], device="cuda"))
+        assert torch.equal(st, torch.get_rng_state())          # invalid rows raise before any draw
+        return
+    if "inline_probs" in case:
+        probs = torch.tensor([case["inline_probs"]], dtype=torch.float32)
+        noise = torch.tensor(case["inline_noise"], dtype=torch.float32)
+    else:
+        probs = oracle.norm_logits(logits_row(case["seed"], case["V"]), case["T"], case["k"], case["p"])
+        noise = torch.from_numpy(G2[case["id"] + "_noise"].copy())
+    rp = hip.noise.ReplayNoise([("exp", noise)], "cuda")
+    tok = hip.S.sample(probs.cuda(), noise=rp)
+    assert int(tok) == case["token"]
+
+
+def test_sample_live_generator_matches_reference_cpu(hip):
+    """Default noise = torch's global CPU generator: same token as torch.multinomial on CPU."""
+    for s in range(6):
+        p = oracle.norm_logits(logits_row(900 + s, 32000), 1.0, 20, 0.9)
+        torch.manual_seed(s)
+        want = torch.multinomial(p, 1)
+        torch.manual_seed(s)
+        got = hip.S.sample(p.cuda())
+        assert int(got) == int(want)
+
+
+@pytest.mark.parametrize("case", [c for c in G2_META["max_fn"] if c["id"] != "p_equals_q"],
+                         ids=lambda c: c["id"])
+def test_max_fn_golden(hip, case):
+    i = int(case["id"][1:])
+    V = case["V"]
+    pr = oracle.norm_logits(logits_row(case["seed_p"], V), case["T"], case["k"], case["p"])
+    qr = oracle.norm_logits(logits_row(case["seed_p"], V) + case["mix"] * logits_row(case["seed_q"], V, 1.0),
+                            case["T"], case["k"], case["p"])
+    got = hip.S.max_fn((pr - qr).cuda()).cpu().numpy()[0]
+    want = dense_from_sparse(V, G2[f"m{i}_idx"], G2[f"m{i}_val"])
+    np.testing.assert_array_equal(got > 0, want > 0)
+    np.testing.assert_allclose(got, want, atol=1e-6, rtol=1e-6)
+
+
+def test_device_philox_sampling_statistics(hip):
+    """Throughput-mode RNG: chi-square of token marginals against the distribution (not bit parity)."""
+    V = 64
+    p = torch.softmax(torch.linspace(0, 3, V), 0)[None]
+    pc = p.cuda()
+    nz = hip.noise.DeviceNoise(seed=1234)
+    n = 4000
+    counts = np.zeros(V)
+    for _ in range(n):
+        counts[int(hip.S.sample(pc, noise=nz))] += 1
+    exp = p.numpy()[0] * n
+    chi2 = float(((counts - exp) ** 2 / exp).sum())
+    assert chi2 < 130.0, chi2          # dof 63: mean 63, p(chi2 > 130) ~ 1e-6
+
+
+# --------------------------------------------------------------------------- G4 accept / resample kernels
+class TableModel:
+    def __init__(self, table):
+        from types import SimpleNamespace
+        self.table = table
+        self.config = SimpleNamespace(is_encoder_decoder=False)
+        self.device = torch.device("cpu")
+
+    def __call__(self, ids, past_key_values=None, use_cache=True):
+        from types import SimpleNamespace
+        past = past_key_values[0][0].shape[2] if past_key_values else 0
+        q = ids.shape[1]
+        kv = torch.zeros(1, 1, past + q, 1)
+        return SimpleNamespace(logits=self.table[past:past + q][None].clone(), past_key_values=[(kv, kv)])
+
+
+G4_META, G4 = load("g4_accept")
+
+
+@pytest.mark.parametrize("case", G4_META, ids=[c["id"] for c in G4_META])
+def test_accept_resample_kernels_golden(hip, case):
+    """The reference's own traces over position-table models: the probability rows are a pure function of
+    the position, so they are normalised once by the HIP norm kernel and the accept-scan / resample
+    kernels then have to reproduce every (accepted count, next token) of the recorded trace."""
+    rng = np.random.default_rng(case["table_seed"])
+    V, S, L0, gamma = case["V"], case["S"], case["L"], case["gamma"]
+    z = rng.standard_normal((S, V), dtype=np.float32) * 2.0
+    eps = rng.standard_normal((S, V), dtype=np.float32) * 2.0
+    prompt = rng.integers(3, V, size=(1, L0))
+    q_hist = hip.S.norm_logits(torch.from_numpy(z).cuda(), 1.0, case["top_k"], case["top_p"])
+    p_hist = hip.S.norm_logits(torch.from_numpy(z + np.float32(case["sigma"]) * eps).cuda(), 1.0,
+                               case["top_k"], case["top_p"])
+    nz = hip.noise.ReplayNoise(events(G4, case["id"]), "cuda")
+    want = G4[case["id"] + "_out"]
+    seq = torch.zeros(S + 8, dtype=torch.int32, device="cuda")
+    seq[:L0] = torch.from_numpy(prompt[0].astype(np.int32)).cuda()
+    host = list(prompt[0])
+    T = L0 + case["max_len"]
+    res = torch.zeros(C.sizeof(hip.L.SdAcceptResult), dtype=torch.uint8, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    acc_len = []
+    lib = hip.lib
+    while len(host) < T:
+        L = len(host)
+        for i in range(gamma):
+            e = nz.exponential(V)
+            hip.L.check(lib.sd_sample(q_hist[L + i - 1].data_ptr(), V, e.data_ptr(), 0, 0, seq[L + i].data_ptr(),
+                                      err.data_ptr(), _st()))
+        nz.skip_exponential(V)                                    # discarded target sample
+        r, token = nz.uniforms(gamma, case["random_seed"])
+        hip.L.check(lib.sd_accept_scan(p_hist.data_ptr(), q_hist.data_ptr(), V, seq.data_ptr(), L, gamma,
+                                       r.data_ptr(), 0, 0, res.data_ptr(), _st()))
+        out = hip.L.SdAcceptResult.from_buffer_copy(res.cpu().numpy().tobytes())
+        nz.realign(token, min(out.n_accepted + 1, gamma))
+        e = nz.exponential(V)
+        hip.L.check(lib.sd_resample(p_hist.data_ptr(), q_hist.data_ptr(), V, V, seq.data_ptr(), L, gamma,
+                                    e.data_ptr(), 0, 0, res.data_ptr(), None, _st()))
+        out = hip.L.SdAcceptResult.from_buffer_copy(res.cpu().numpy().tobytes())
+        assert not (out.flags & 2)
+        acc_len.append(out.n_accepted)
+        host = host + seq[L:L + out.n_accepted].cpu().tolist() + [out.next_token]
+        assert out.n == L + out.n_accepted - 1
+    assert acc_len == case["acc_len"]
+    np.testing.assert_array_equal(np.array(host, dtype=np.int32), want)
+    assert nz.exhausted()
+
+
+def test_resample_fallback_when_residual_is_zero(hip):
+    """p == q at the rejected position: max_fn(p-q) is all zero, the reference's sample raises and it
+    falls back to sample(max_fn(p)) (speculative_sampling.py:2007-2010)."""
+    V, L, gamma = 128, 3, 2
+    p = oracle.norm_logits(logits_row(77, V), 1.0, 10, 0.0)
+    hist = p.repeat(8, 1).cuda()
+    seq = torch.zeros(16, dtype=torch.int32, device="cuda")
+    nzidx = int(torch.nonzero(p[0])[0])
+    seq[L] = nzidx
+    seq[L + 1] = nzidx
+    r = torch.tensor([2.0, 2.0], device="cuda")                  # force a reject at i = 0
+    res = torch.zeros(C.sizeof(hip.L.SdAcceptResult), dtype=torch.uint8, device="cuda")
+    noise = torch.empty(V).exponential_(1)
+    hip.L.check(hip.lib.sd_accept_scan(hist.data_ptr(), hist.data_ptr(), V, seq.data_ptr(), L, gamma, r.data_ptr(),
+                                       0, 0, res.data_ptr(), _st()))
+    hip.L.check(hip.lib.sd_resample(hist.data_ptr(), hist.data_ptr(), V, V, seq.data_ptr(), L, gamma,
+                                    noise.cuda().data_ptr(), 0, 0, res.data_ptr(), None, _st()))
+    out = hip.L.SdAcceptResult.from_buffer_copy(res.cpu().numpy().tobytes())
+    assert out.n_accepted == 0 and out.n == L - 1 and (out.flags & 1)
+    want = oracle.sample(oracle.max_fn(p), oracle.RecordedNoise([("exp", noise[None])]))
+    assert out.next_token == int(want)
+
+
+# --------------------------------------------------------------------------- G6 logits
+G6_META, G6 = load("g6_logits")
+
+
+def _engine_model(hip, cfg_name, seed, dtype, sd=None):
+    cfg = load_config(cfg_name)
+    sd = sd if sd is not None else make_state_dict(cfg, seed, dtype=dtype)
+    return cfg, hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+
+
+@pytest.mark.parametrize("case", G6_META, ids=[c["id"] for c in G6_META])
+def test_forward_logits_golden(hip, case):
+    """Prefill + incremental forwards (q = 12, 1, 2, 5 new rows) against the reference model classes."""
+    dtype = DT[case["dtype"]]
+    cfg, m = _engine_model(hip, case["cfg"], case["seed"], dtype)
+    ses = m.new_session(64)
+    ids = torch.from_numpy(G6[case["id"] + "_ids"]).cuda()
+    pos = 0
+    tol = 1e-3 if dtype == torch.float32 else 0.25
+    for si, q in enumerate(case["splits"]):
+        out = torch.empty((q, cfg.vocab_size), dtype=torch.float32, device="cuda")
+        ses.forward(ids[pos:pos + q], q, logits_out=out)
+        want = G6[f"{case['id']}_s{si}"]
+        np.testing.assert_allclose(out.cpu().numpy(), want, atol=tol, rtol=0)
+        pos += q
+    assert ses.cache_len == 20
+    k0 = ses.past_key_values()[0][0]
+    assert list(k0.shape) == case["kv_shape"]                     # the reference's (1, H_kv, S, D) view
+
+
+def test_forward_rollback_is_pure(hip):
+    """Rolling the arena back and re-feeding gives bit-identical logits (rollback = length counter)."""
+    cfg, m = _engine_model(hip, "tiny-llama-target", 12, torch.float32)
+    ses = m.new_session(64)
+    ids = torch.from_numpy(G6["tiny-llama-target_float32_ids"]).cuda()
+    a = ses.forward(ids[:12], 1).clone()
+    b = ses.forward(ids[12:17], 5).clone()
+    ses.rollback(12)
+    b2 = ses.forward(ids[12:17], 5).clone()
+    assert torch.equal(b, b2)
+    ses.rollback(0)
+    a2 = ses.forward(ids[:12], 1).clone()
+    assert torch.equal(a, a2)
+
+
+# --------------------------------------------------------------------------- G5 end-to-end traces
+G5_META, G5 = load("g5_traces")
+
+
+@pytest.mark.parametrize("case", G5_META["spec"], ids=[c["id"] for c in G5_META["spec"]])
+def test_speculative_trace_golden(hip, case):
+    """speculative_sampling through the HIP engine, fed the noise the reference consumed: the token ids,
+    accepted lengths and call counts of the reference's own run must come out."""
+    dcfg, dsd, tcfg, tsd = model_pair(case)
+    dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+    tm = dm if case["target_spec"][0] == "same" else hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.float32)
+    prompt = torch.from_numpy(G5[case["id"] + "_prompt"].astype(np.int64))[None].cuda()
+    nz = hip.noise.ReplayNoise(events(G5, case["id"]), "cuda")
+    out, d = hip.S.speculative_sampling(prompt, dm, tm, case["eos"], None, case["max_len"], details=True, rng=nz,
+                                        **case["kwargs"])
+    np.testing.assert_array_equal(out.cpu().numpy()[0], G5[case["id"] + "_out"])
+    assert d["acc_len"] == case["acc_len"]
+    assert d["target_call_times"] == case["target_call_times"]
+    assert d["approx_call_times"] == case["approx_call_times"]
+    assert abs(float(d["acc_rate"]) - case["acc_rate"]) < 1e-4
+    assert nz.exhausted()
+    assert out.dtype == torch.int64 and out.shape[0] == 1
+
+
+def test_speculative_live_host_rng_matches_reference_seed(hip):
+    """rng="host": with the same outer torch.manual_seed the reference used, the tokens of its run come out
+    (this is the drop-in's default mode)."""
+    for cid in ("llama_corr", "llama_seeded", "opt_post_pair"):
+        case = [c for c in G5_META["spec"] if c["id"] == cid][0]
+        dcfg, dsd, tcfg, tsd = model_pair(case)
+        dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+        tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.float32)
+        prompt = torch.from_numpy(G5[cid + "_prompt"].astype(np.int64))[None].cuda()
+        torch.manual_seed(case["outer_seed"])
+        out = hip.S.speculative_sampling(prompt, dm, tm, case["eos"], None, case["max_len"], **case["kwargs"])
+        np.testing.assert_array_equal(out.cpu().numpy()[0], G5[cid + "_out"])
+
+
+@pytest.mark.parametrize("case", G5_META["ar"], ids=[c["id"] for c in G5_META["ar"]])
+def test_autoregressive_trace_golden(hip, case):
+    cfg = load_config(case["cfg"])
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, make_state_dict(cfg, case["seed"]), dtype=torch.float32)
+    prompt = torch.from_numpy(G5[case["id"] + "_prompt"].astype(np.int64))[None].cuda()
+    nz = hip.noise.ReplayNoise(events(G5, case["id"]), "cuda")
+    out = hip.S.autoregressive_sampling(prompt, m, case["N"], case["eos"], rng=nz, **case["kwargs"])
+    np.testing.assert_array_equal(out.cpu().numpy()[0], G5[case["id"] + "_out"])
+
+
+def test_kvcache_model_api_matches_oracle(hip):
+    """KVCacheModel drop-in: generate / rollback / _prob_history / _past_key_values against the oracle wrapper."""
+    cfg = load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 12)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    prompt = torch.from_numpy(np.random.default_rng(5).integers(3, cfg.vocab_size, size=(1, 9)))
+    rec = oracle.RecordingNoise()
+    torch.manual_seed(3)
+    okv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1.0, 20, 0.9, noise=rec)
+    ox = okv.generate(prompt, 4)
+    kv = hip.S.KVCacheModel(m, 1.0, 20, 0.9, noise=hip.noise.ReplayNoise(rec.events, "cuda"))
+    x = kv.generate(prompt.cuda(), 4)
+    assert torch.equal(x.cpu(), ox)
+    assert kv._prob_history.shape == okv._prob_history.shape
+    assert float((kv._prob_history.cpu() - okv._prob_history).abs().max()) < 1e-5
+    k, v = kv._past_key_values[0]
+    ok, ov = okv._past_key_values[0]
+    assert k.shape == ok.shape and float((k.cpu() - ok).abs().max()) < 1e-4
+    kv.rollback(10)
+    okv.rollback(10)
+    assert kv._prob_history.shape == okv._prob_history.shape == (1, 10, cfg.vocab_size)
+    assert kv._past_key_values[0][0].shape == okv._past_key_values[0][0].shape
+    for name in ("forward_tree_attention", "beam_rollback", "rollback_tree_attention", "beam_sample"):
+        with pytest.raises(NotImplementedError):
+            getattr(kv, name)()
+
+
+def test_batch_size_assert(hip):
+    cfg = load_config("tiny-llama-draft")
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, make_state_dict(cfg, 21), dtype=torch.float32)
+    with pytest.raises(AssertionError, match="input batch size must be 1"):
+        hip.S.speculative_sampling(torch.ones(2, 4, dtype=torch.int64).cuda(), m, m, 2, None, 4)
