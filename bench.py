@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Headline benchmark: accepted tokens/sec + mean accept-len of speculative_sampling,
+llama-68m -> Llama-2-13b, gamma = 4, bf16, prompt 128, max_len 128 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one speculative_sampling() call over one prompt stream (SURVEY.md 8(d) C2 / C4 inputs:
+stream s has prompt seed 1000+s and RNG seed 2000+s).  Streams are independent, so ranks shard them
+with no collective on the data path; one all_gather of token ids at the end of the timed region
+(SURVEY.md 8(e)).  Weights are random-init from the committed config JSONs (no checkpoints offline), so the
+accept length is ~0 by construction and `value` is essentially 1 token per draft+verify iteration;
+`mean_accept_len` is reported next to it.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--draft", default="llama-68m")
+    ap.add_argument("--target", default="llama-2-13b")
+    ap.add_argument("--gamma", type=int, default=4)
+    ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--max-len", type=int, default=128)
+    ap.add_argument("--top-k", type=int, default=20)
+    ap.add_argument("--top-p", type=float, default=0.9)
+    ap.add_argument("--rng", default="device", choices=["device", "host"],
+                    help="device = on-device Philox (throughput mode); host = torch CPU generator in the reference's order")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on a bounded sample (rank 0, N=1)")
+    ap.add_argument("--cpu-max-len", type=int, default=6)
+    ap.add_argument("--cpu-prompt-len", type=int, default=128)
+    ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
+    return ap.parse_args()
+
+
+def algorithmic_verify_bytes(cfg, gamma, S, wbytes=2, kvbytes=2):
+    """B_verify = W_stream*b_w + KV read at context S + KV write of gamma+1 rows + logits."""
+    w = cfg.n_params(streamed_only=True) * wbytes
+    kv_row = 2 * cfg.num_hidden_layers * cfg.num_key_value_heads * cfg.head_dim * kvbytes
+    return w + kv_row * S + kv_row * (gamma + 1) + (gamma + 1) * cfg.vocab_size * 4
+
+
+def prompt_for(stream, V, L):
+    g = torch.Generator().manual_seed(1000 + stream)
+    return torch.randint(3, V, (1, L), generator=g)
+
+
+def cpu_baseline(args, dcfg, tcfg, dm, tm):
+    """The oracle (torch-CPU restatement, pinned to the reference by tests/golden) on the host cores,
+    same weights, same dtype, a bounded sample of the same workload."""
+    import oracle
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    torch.set_num_threads(ncores)
+    t0 = time.time()
+    dsd = {n: dm._synth_get(n).cpu() for n in dm._synth_names}
+    tsd = {n: tm._synth_get(n).cpu() for n in tm._synth_names}
+    for sd in (dsd, tsd):
+        if "model.decoder.embed_tokens.weight" in sd:
+            sd["lm_head.weight"] = sd["model.decoder.embed_tokens.weight"]
+    t_copy = time.time() - t0
+    od, ot = oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd)
+    prompt = prompt_for(0, tcfg.vocab_size, args.cpu_prompt_len)
+    torch.manual_seed(2000)
+    w0, p0 = time.time(), time.process_time()
+    out, d = oracle.speculative_sampling(prompt, od, ot, 2, None, args.cpu_max_len, gamma=args.gamma,
+                                         top_k=args.top_k, top_p=args.top_p, details=True)
+    wall, cpu = time.time() - w0, time.process_time() - p0
+    new = int(out.shape[1] - prompt.shape[1])
+    iters = d["target_call_times"]
+    # split: first iteration carries both prefills
+    return {
+        "value": new / wall, "unit": "tokens/s", "cores": ncores, "kind": "port",
+        "sample": (f"oracle.speculative_sampling, same random-init bf16 weights copied from the GPU, prompt "
+                   f"{args.cpu_prompt_len}, max_len {args.cpu_max_len} (vs {args.max_len} on the GPU), gamma {args.gamma}: "
+                   f"{new} tokens in {wall:.1f} s wall / {cpu:.1f} s process_time over {iters} iterations; "
+                   f"weight copy {t_copy:.1f} s not timed"),
+        "wall_s": wall, "process_time_s": cpu, "iterations": iters,
+        "mean_accept_len": float(np.mean(d["acc_len"])) if d["acc_len"] else 0.0,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from llmspeculativesampling_amd.config import load_config
+    from llmspeculativesampling_amd.engine import SpecDecModel
+    from llmspeculativesampling_amd.noise import DeviceNoise, HostTorchNoise
+    from llmspeculativesampling_amd.sampling import speculative_sampling
+
+    dcfg, tcfg = load_config(args.draft), load_config(args.target)
+    max_pos = args.prompt_len + args.max_len + args.gamma + 8
+    t0 = time.time()
+    dm = SpecDecModel.synthetic(dcfg, seed=1, dtype=torch.bfloat16, max_pos=max_pos)
+    tm = SpecDecModel.synthetic(tcfg, seed=2, dtype=torch.bfloat16, max_pos=max_pos)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_step(stream, logs=None):
+        prompt = prompt_for(stream, tcfg.vocab_size, args.prompt_len).cuda()
+        if args.rng == "device":
+            nz = DeviceNoise(seed=2000 + stream)
+        else:
+            torch.manual_seed(2000 + stream)
+            nz = HostTorchNoise(prompt.device)
+        out, d = speculative_sampling(prompt, dm, tm, eos_token_id=2, pad_token_id=None, max_len=args.max_len,
+                                      gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True, rng=nz,
+                                      _event_logs=logs)
+        return out, d
+
+    # streams: rank r takes s = r, r+world, ... (round-robin)
+    for i in range(args.warmup):
+        run_step(rank + 10_000 * (i + 1))
+    barrier()
+    t0 = time.time()
+    new_tokens, acc_sum, n_iters = 0, 0, 0
+    logs = ([], [])
+    outs = []
+    for i in range(args.steps):
+        out, d = run_step(rank + i * world, logs)
+        new_tokens += int(out.shape[1]) - args.prompt_len
+        acc_sum += int(sum(d["acc_len"]))
+        n_iters += int(d["target_call_times"])
+        outs.append(out)
+    if dist is not None:
+        # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
+        width = args.prompt_len + args.max_len + args.gamma + 1
+        mine = torch.full((args.steps, width), -1, dtype=torch.int32, device="cuda")
+        for i, o in enumerate(outs):
+            mine[i, : o.shape[1]] = o[0].to(torch.int32)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    barrier()
+    elapsed = time.time() - t0
+    stats = torch.tensor([elapsed, float(new_tokens), float(acc_sum), float(n_iters)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, (new_tokens, acc_sum, n_iters) = float(tmax[0]), [float(x) for x in tot]
+    value = new_tokens / elapsed
+
+    # ---- verify-step roofline from the HIP events recorded inside the timed region (torch's current stream is
+    # the stream every kernel was launched on).  One "launch" = one verify step = one target forward over
+    # gamma+1 rows + norm_probs, a fixed chain of kernels; algorithmic bytes per SURVEY.md 8(d).
+    ver_ms, ver_S, pre_ms = [], [], []
+    for (e0, e1, n_new, upto) in logs[1]:
+        (ver_ms if n_new == args.gamma + 1 else pre_ms).append(e0.elapsed_time(e1))
+        if n_new == args.gamma + 1:
+            ver_S.append(upto)
+    drf_ms = [e0.elapsed_time(e1) for (e0, e1, n_new, _) in logs[0] if n_new <= 2]
+    t_ver = float(np.mean(ver_ms)) if ver_ms else float("nan")
+    S_mean = float(np.mean(ver_S)) if ver_S else float(args.prompt_len + args.max_len / 2)
+    b_ver = algorithmic_verify_bytes(tcfg, args.gamma, S_mean)
+    achieved = b_ver / (t_ver * 1e-3) / 1e9 if ver_ms else float("nan")
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "kernel": "verify step (target forward over gamma+1 rows: gemm_bf16_stream chain + attention + epilogues + norm_probs)",
+        "algorithmic_bytes_per_launch": b_ver, "avg_launch_ms": t_ver, "launches_timed": len(ver_ms),
+        "mean_context": S_mean,
+        "draft_step_avg_ms": float(np.mean(drf_ms)) if drf_ms else None,
+        "target_prefill_avg_ms": float(np.mean(pre_ms)) if pre_ms else None,
+    }
+
+    # ---- per-op-class split of one verify step (events around every launch; outside the timed region)
+    if args.profile_classes and rank == 0:
+        ses = tm.new_session(max_pos)
+        toks = prompt_for(0, tcfg.vocab_size, args.prompt_len + args.gamma + 1).cuda()[0].to(torch.int32)
+        done = 0
+        while done < args.prompt_len:
+            m = min(64, args.prompt_len - done)
+            ses.forward(toks[done:done + m], 0)
+            done += m
+        for _ in range(2):
+            ses.rollback(args.prompt_len)
+            ses.forward(toks[args.prompt_len:], args.gamma + 1)
+        torch.cuda.synchronize()
+        ses.profile(True)
+        reps = 3
+        for _ in range(reps):
+            ses.rollback(args.prompt_len)
+            ses.forward(toks[args.prompt_len:], args.gamma + 1)
+        prof = ses.profile_read()
+        ses.profile(False)
+        wbytes = tm.weight_bytes
+        roofline["op_classes_ms_per_verify"] = {k: v[0] / reps for k, v in prof.items()}
+        roofline["op_classes_launches_per_verify"] = {k: v[1] // reps for k, v in prof.items()}
+        if "gemm" in prof:
+            g_ms = prof["gemm"][0] / reps
+            roofline["gemm_kernel"] = {"name": "gemm_bf16_stream<1,8>", "weight_bytes_per_verify": wbytes,
+                                       "ms_per_verify": g_ms, "achieved_GBs": wbytes / (g_ms * 1e-3) / 1e9,
+                                       "frac": wbytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    result = {
+        "metric": "accepted tokens/sec (speculative_sampling, llama-68m -> Llama-2-13b, gamma=4)",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt {args.prompt_len}, "
+                               f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, 1 stream per step per GPU, "
+                               f"rng={args.rng}; random-init weights (accept-len ~0 by construction)",
+                   "streams": args.steps * world, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+        "mean_accept_len": acc_sum / max(1.0, n_iters), "iterations": n_iters, "new_tokens": new_tokens,
+        "roofline": roofline, "model_build_s": t_build,
+    }
+
+    if args.cpu_baseline and rank == 0 and world == 1:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, dcfg, tcfg, dm, tm)
+        except Exception as e:          # never lose the GPU numbers to a host-side failure
+            result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port",
+                                      "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -193,7 +193,9 @@ class SpecDecModel:
             gen.manual_seed(int(seed) * 100003 + idx)
             t = torch.empty(shape, dtype=torch.float32 if dtype == torch.float32 else torch.bfloat16, device=device)
             return t.normal_(mean, std, generator=gen)
-        return cls(cfg, get, dtype=dtype, device=device, max_pos=max_pos)
+        m = cls(cfg, get, dtype=dtype, device=device, max_pos=max_pos)
+        m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
+        return m
 
     def export_state_dict(self) -> Dict[str, torch.Tensor]:
         raise NotImplementedError

@@ -36,6 +36,7 @@ class KVCacheModel:
         self._tok32: Optional[torch.Tensor] = None
         self._hist_len = 0                              # rows of _probs that are in the history
         self._hist_lo = 0                               # first row that was actually normalised
+        self.event_log = None                           # bench: list of (start_evt, end_evt, n_new, upto) per forward
 
     # -- lazily sized arenas ----------------------------------------------------------------
     def _ensure(self, need: int):
@@ -81,6 +82,10 @@ class KVCacheModel:
         st = _stream()
         V = self._model.cfg.vocab_size
         first = upto - n_rows_out
+        ev0 = None
+        if self.event_log is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         while done < n_rows_out:                        # logits buffer holds max_rows rows at a time
             # feed everything up to the end of this block of output rows
             blk = min(ses.max_rows, n_rows_out - done)
@@ -95,6 +100,10 @@ class KVCacheModel:
             self.forward_time_dict["_model_time"] += t1 - t0
             t0 = process_time_ns()
             done += blk
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.event_log.append((ev0, ev1, n_new, upto))
         if self._hist_len == 0:
             self._hist_lo = first
         self._hist_len = upto

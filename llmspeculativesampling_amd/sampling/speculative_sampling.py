@@ -31,7 +31,8 @@ def _make_noise(rng, device):
 @torch.no_grad()
 def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_token_id, pad_token_id,
                          max_len: int, gamma: int = 4, temperature: float = 1, top_k: int = 0, top_p: float = 0,
-                         verbose: bool = False, random_seed: int = None, details: bool = False, *, rng=None):
+                         verbose: bool = False, random_seed: int = None, details: bool = False, *, rng=None,
+                         _event_logs=None):
     """reference speculative_sampling.py:1876-2076.
 
     ``rng`` (extension): "host" (default) draws every variate from torch's CPU generator in the
@@ -58,6 +59,8 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
     target = KVCacheModel(target_m, temperature, top_k, top_p, max_seq=cap, noise=noise, full_history=False)
     draft._ensure(cap)
     target._ensure(cap)
+    if _event_logs is not None:                       # bench.py: HIP-event brackets around every forward
+        draft.event_log, target.event_log = _event_logs
     seq32 = torch.zeros(cap + 1, dtype=torch.int32, device=dev)
     seq32[:seq_len0] = prefix[0].to(device=dev, dtype=torch.int32)
     res_dev = torch.zeros(C.sizeof(SdAcceptResult), dtype=torch.uint8, device=dev)

@@ -51,11 +51,15 @@ def test_norm_probs_golden(hip, case):
             case["V"], G1[case["id"] + "_idx"], G1[case["id"] + "_val"])
     got = hip.S.norm_logits(x.cuda(), case["T"], case["k"], case["p"]).cpu().numpy()[0]
     np.testing.assert_array_equal(got > 0, want > 0)            # identical support set
-    np.testing.assert_allclose(got, want, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(got, want, atol=1e-6, rtol=5e-6)
 
 
 def test_norm_probs_many_rows_vs_oracle(hip):
-    """Random rows, several (T,k,p) incl. the general top-p path (no top-k) at V = 32000 / 50272."""
+    """Random rows, several (T,k,p) incl. the general top-p path (no top-k) at V = 32000 / 50272.
+
+    Tolerance: 1e-6 absolute + 5e-6 relative.  The relative part is the reference's own rounding: torch's
+    fp32 row sum over V = 32000 is off by up to 2.5e-6 relative (its probabilities differ from the fp64
+    softmax by 1.3e-6 on these rows, measured); the HIP kernel is held to 2.5e-7 of the fp64 result below."""
     for V in (1000, 32000, 50272):
         for (T, k, p) in [(1.0, 20, 0.9), (0.8, 0, 0.9), (1.0, 0, 0.0), (1.0, 2000, 0.99), (1.0, 50, 0.0)]:
             rows = torch.cat([logits_row(4242 + i, V, 3.0) for i in range(3)], 0)
@@ -63,7 +67,10 @@ def test_norm_probs_many_rows_vs_oracle(hip):
             for i in range(rows.shape[0]):
                 want = oracle.norm_logits(rows[i:i + 1], T, k, p)[0]
                 assert torch.equal(got[i] > 0, want > 0), (V, T, k, p, i)
-                assert float((got[i] - want).abs().max()) <= 1e-6
+                np.testing.assert_allclose(got[i].numpy(), want.numpy(), atol=1e-6, rtol=5e-6)
+                z = torch.where(want > 0, (rows[i] / T).double(), torch.full((V,), float("-inf"), dtype=torch.float64))
+                exact = torch.softmax(z, 0)
+                assert float((got[i].double() - exact).abs().max()) <= 2.5e-7, (V, T, k, p, i)
 
 
 # --------------------------------------------------------------------------- G2 sample / G3 max_fn
@@ -191,6 +198,9 @@ def test_accept_resample_kernels_golden(hip, case):
         acc_len.append(out.n_accepted)
         host = host + seq[L:L + out.n_accepted].cpu().tolist() + [out.next_token]
         assert out.n == L + out.n_accepted - 1
+        if 2 in host[L0:]:                                         # EOS rule (eos = 2, none in the prompt)
+            host = host[:L0 + host[L0:].index(2) + 1]
+            break
     assert acc_len == case["acc_len"]
     np.testing.assert_array_equal(np.array(host, dtype=np.int32), want)
     assert nz.exhausted()
