@@ -146,6 +146,13 @@ int sd_model_destroy(sd_model *m);
  * GEMM kernels read: 1 KiB tiles [N/16][K/32][lane 0..63][8 bf16], lane = 16*(k/8 % 4) + n % 16. */
 int sd_pack_weight_bf16(const void *w_rowmajor, void *w_packed, int N, int K, void *stream);
 
+/* The weight-streaming GEMM on its own (unit tests, kernel-level roofline runs):
+ * part[s][m][n] = sum over k-slice s of x[m][k] * W[n][k] for a tile-packed bf16 W, then (if out != NULL)
+ * out[m][n] = sum_s part[s][m][n] in fp32.  M <= 64.  part must hold splits * roundup(M,16) * N floats;
+ * the split count the policy chose comes back in *splits_out. */
+int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, int K, float *part, size_t part_floats,
+                 float *out, int *splits_out, void *stream);
+
 /* A session = one KV arena + scratch for one sequence (one KVCacheModel of the reference).
  * kv_arena: [n_layers][2][n_kv_heads][max_seq][head_dim] in `dtype`, caller-allocated.
  * scratch: sd_session_scratch_bytes() bytes, caller-allocated. */

@@ -63,6 +63,7 @@ extern "C" int sd_model_create(const sd_model_config *cfg, const sd_model_weight
     SD_REQUIRE(cfg->head_dim == 16 || cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128,
                "sd_model_create: head_dim %d not in {16,32,64,128}", cfg->head_dim);
     SD_REQUIRE(cfg->n_heads * cfg->head_dim == cfg->hidden, "sd_model_create: n_heads*head_dim != hidden");
+    SD_REQUIRE(cfg->hidden % 4 == 0, "sd_model_create: hidden %% 4 != 0");
     SD_REQUIRE(cfg->n_kv_heads > 0 && cfg->n_heads % cfg->n_kv_heads == 0, "sd_model_create: bad n_kv_heads");
     if (cfg->dtype == SD_BF16) {
         SD_REQUIRE(cfg->hidden % 32 == 0 && cfg->inter % 32 == 0 && cfg->vocab % 16 == 0 && cfg->opt_proj_dim % 32 == 0,
@@ -331,6 +332,7 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
     const size_t layer_kv = (size_t)2 * c.n_kv_heads * s->max_seq * D;      // elements per layer
     const int pos_off = 2;                                                   // OPT offset (modeling_opt.py:104)
+    const int rn_threads = (int)std::min<size_t>(1024, std::max<size_t>(64, align_up(H / 4, 64)));
     GemmOut go;
     int rc;
 
@@ -394,7 +396,7 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
             const int mode = pre ? RES_PRE : RES_POST;
             const T *nw = pre ? (const T *)m->n2w[l] : (const T *)m->n1w[l];
             const T *nb = pre ? (const T *)m->n2b[l] : (const T *)m->n1b[l];
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), norm_lds, st, x, s->part, go.S,
                                go.stride_s, H, (const T *)m->bo[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }
@@ -418,7 +420,7 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
             } else {
                 mode = RES_POST; nw = (const T *)m->n2w[l]; nb = (const T *)m->n2b[l];
             }
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), norm_lds, st, x, s->part, go.S,
                                go.stride_s, H, (const T *)m->bfc2[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }
@@ -458,4 +460,35 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     if (s->m->cfg.dtype == SD_BF16)
         return forward_impl<bf16_t>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
     return forward_impl<float>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
+}
+
+// ---- standalone weight-streaming GEMM (unit tests + kernel-level roofline runs) --------------
+__global__ void reduce_f32_kernel(const float *__restrict__ part, int S, size_t stride_s, int total,
+                                  float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    out[i] = reduce_part<float>(part, S, stride_s, (size_t)i, nullptr, 0);
+}
+
+extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, int K, float *part,
+                            size_t part_floats, float *out, int *splits_out, void *stream) {
+    SD_REQUIRE(w_packed && x && part, "sd_gemm_bf16: null argument");
+    SD_REQUIRE(M >= 1 && M <= 64 && N % 16 == 0 && K % 32 == 0, "sd_gemm_bf16: need 1<=M<=64, N%%16==0, K%%32==0");
+    int S, ksp;
+    gemm_split(N, K, &S, &ksp);
+    const int Mpad = (int)align_up(M, 16);
+    SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
+    hipStream_t st = (hipStream_t)stream;
+    const int MT = Mpad / 16;
+    if (MT == 1) launch_gemm_bf16<1>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
+    else if (MT == 2) launch_gemm_bf16<2>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
+    else launch_gemm_bf16<4>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
+    SD_LAUNCH_CHECK();
+    if (out) {
+        hipLaunchKernelGGL(reduce_f32_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, S,
+                           (size_t)Mpad * N, M * N, out);
+        SD_LAUNCH_CHECK();
+    }
+    if (splits_out) *splits_out = S;
+    return SD_OK;
 }

@@ -116,10 +116,49 @@ __global__ void pack_weight_kernel(const uint16_t *__restrict__ src, uint16_t *_
 template <typename T>
 __device__ __forceinline__ float reduce_part(const float *__restrict__ part, int S, size_t stride_s, size_t off,
                                              const T *__restrict__ bias, int col) {
+    const float *p = part + off;
     float a = 0.f;
-    for (int s = 0; s < S; ++s) a += part[(size_t)s * stride_s + off];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {                                  // 8 independent loads in flight, fixed add order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + u) * stride_s];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s + 4 <= S; s += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = p[(size_t)(s + u) * stride_s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+    }
+    for (; s < S; ++s) a += p[(size_t)s * stride_s];
     if (bias) a += to_f(bias[col]);
     return rnd<T>(a);
+}
+
+// Same for 4 consecutive columns (16-byte loads); off must be a multiple of 4.
+__device__ __forceinline__ f32x4 reduce_part4(const float *__restrict__ part, int S, size_t stride_s, size_t off) {
+    const float *p = part + off;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(s + u) * stride_s);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; s + 4 <= S; s += 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(s + u) * stride_s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += v[u];
+    }
+    for (; s < S; ++s) a += *reinterpret_cast<const f32x4 *>(p + (size_t)s * stride_s);
+    return a;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -207,22 +246,27 @@ __global__ __launch_bounds__(256) void norm_kernel(const T *__restrict__ x, int 
 // x' = rnd(x + rnd(sum part + bias)); then per mode: PRE: x <- x', h <- norm(x');  POST: x,h <- LN(x');
 // NONE: x,h <- x'.   (residual adds: modeling_llama.py:440,446; modeling_opt.py:342-347, 363-368)
 template <typename T>
-__global__ __launch_bounds__(256) void residual_norm_kernel(T *__restrict__ x, const float *__restrict__ part, int S,
-                                                           size_t stride_s, int H, const T *__restrict__ bias,
-                                                           const T *__restrict__ w, const T *__restrict__ b,
-                                                           float eps, int kind, int mode, T *__restrict__ h) {
+__global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, const float *__restrict__ part, int S,
+                                                            size_t stride_s, int H, const T *__restrict__ bias,
+                                                            const T *__restrict__ w, const T *__restrict__ b,
+                                                            float eps, int kind, int mode, T *__restrict__ h) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     float *red = xs + H;
     const int row = blockIdx.x;
     T *xr = x + (size_t)row * H;
     T *hr = h + (size_t)row * H;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) {
-        const float y = reduce_part<T>(part, S, stride_s, (size_t)row * H + i, bias, i);
-        const float v = rnd<T>(to_f(xr[i]) + y);
-        xs[i] = v;
-        if (mode != RES_POST) xr[i] = from_f<T>(v);
-        if (mode == RES_NONE) hr[i] = from_f<T>(v);
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {     // H % 4 == 0 (checked at model creation)
+        const f32x4 y4 = reduce_part4(part, S, stride_s, (size_t)row * H + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = y4[j];
+            if (bias) y += to_f(bias[i + j]);
+            const float v = rnd<T>(to_f(xr[i + j]) + rnd<T>(y));
+            xs[i + j] = v;
+            if (mode != RES_POST) xr[i + j] = from_f<T>(v);
+            if (mode == RES_NONE) hr[i + j] = from_f<T>(v);
+        }
     }
     __syncthreads();
     if (mode == RES_PRE) norm_row<T>(xs, H, w, b, eps, kind, red, hr, nullptr);
@@ -314,6 +358,39 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, c
     }
     __syncthreads();
 
+    if constexpr (sizeof(T) == 2 && D >= 32) {
+        // bf16: QK^T on the matrix cores.  A = 16 keys x 32 dims straight from the arena, B = q^T (rows >= nr
+        // are zero), so lane l ends up with score[key = 16*kt + 4*(l>>4) + j][row = l&15].
+        const int w = tid >> 6, lane = tid & 63;
+        const int mrow = lane & 15, kq = (lane >> 4) * 8;
+        u32x4 qf[D / 32];
+#pragma unroll
+        for (int dk = 0; dk < D / 32; ++dk)
+            qf[dk] = mrow < nr ? *reinterpret_cast<const u32x4 *>(qbuf + (size_t)(r0 + mrow) * Hq * D + head * D + dk * 32 + kq)
+                               : u32x4{0u, 0u, 0u, 0u};
+        for (int kt = w; kt * 16 < s_hi; kt += 4) {
+            const int key = kt * 16 + mrow;
+            const T *kr = K + (size_t)min(key, s_hi - 1) * D + kq;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dk = 0; dk < D / 32; ++dk) {
+                const u32x4 kf = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                              __builtin_bit_cast(bf16x8, qf[dk]), acc, 0, 0, 0);
+            }
+            if (mrow < ATT_TQ) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = kt * 16 + (lane >> 4) * 4 + j;
+                    if (s < s_hi) {
+                        float v = rnd<T>(acc[j]);
+                        if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
+                        sc[(size_t)mrow * s_cap + s] = (s <= pos0 + r0 + mrow) ? v : -INFINITY;
+                    }
+                }
+            }
+        }
+    } else
     for (int s = tid; s < s_hi; s += 256) {
         float acc[ATT_TQ];
 #pragma unroll
