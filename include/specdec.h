@@ -54,6 +54,14 @@ int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temper
                   float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
                   void *stream);
 
+/* One draft / autoregressive step's tail fused: norm_logits of ONE row followed by sample() on it
+ * (kvcache_model.py:235-236 + :283), a single launch.  Writes the probability row (the accept scan and
+ * the residual need it later) and the sampled token.  exp_noise / Philox as in sd_sample; with device
+ * Philox only the surviving tokens draw a variate.  sample_err as sd_sample's err_flag. */
+int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
+                   int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
+                   uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *stream);
+
 /* sample (utils.py:213-233) for num_samples == 1: argmax_i probs[i] / noise[i] (first index wins
  * ties), then the "< 1e-9 -> argmax(probs)" fix-up.  exp_noise is a device row of Exp(1) variates
  * in the reference's draw order (parity mode), or NULL to draw them on the device from Philox

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("sd_version", _I, []),
     ("sd_last_error", C.c_char_p, []),
     ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP]),
+    ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),

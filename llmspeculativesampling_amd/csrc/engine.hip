@@ -101,15 +101,30 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
     return SD_OK;
 }
 
-// ---- split-K policy: enough (n-tile, k-slice) units to keep >= ~16 waves per CU streaming
+// ---- split-K policy.  A workgroup (4 waves) owns one n-tile x one k-slab and folds its waves in LDS, so
+// SB slabs reach HBM.  SB is chosen so that about `target` workgroups exist (>= 4 per CU), with at least
+// 8 k-steps (8 KiB of weights) per workgroup.
 static void gemm_split(int N, int K, int *S_out, int *ks_per_out) {
     const int NTL = N / 16, KS = K / 32;
-    int S = (4096 + NTL - 1) / NTL;
-    const char *env = getenv("SD_GEMM_UNITS");
-    if (env) S = (atoi(env) + NTL - 1) / NTL;
-    if (S < 1) S = 1;
-    int max_s = KS / 4;                      // at least 4 k-steps (4 KiB of weights) per unit
+    int max_s = KS / 8;
     if (max_s < 1) max_s = 1;
+    int S = 1;
+    const char *env = getenv("SD_GEMM_UNITS");
+    if (env) {
+        S = (atoi(env) + NTL / 2) / NTL;
+    } else if (NTL < 1024) {
+        // fewest slabs that give >= 1024 workgroups, preferring a workgroup count that fills all 256 CUs evenly
+        // (measured on MI355X: 7.5 workgroups per CU runs 10 % slower than 15 per CU, tools/gemm_bench.py)
+        double best = -1.0;
+        for (int c = 1; c <= max_s && c <= 16; ++c) {
+            const int blocks = NTL * c;
+            if (blocks < 1024 && c < max_s && c < 16) continue;
+            const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+            if (eff > best + 1e-9) { best = eff; S = c; }
+            if (blocks >= 4096) break;
+        }
+    }
+    if (S < 1) S = 1;
     if (S > max_s) S = max_s;
     int ks_per = (KS + S - 1) / S;
     S = (KS + ks_per - 1) / ks_per;
@@ -269,8 +284,7 @@ struct GemmOut {
 template <int MT>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
                              int ks_per, hipStream_t st) {
-    const int units = (N / 16) * S;
-    const int blocks = (units + 3) / 4;
+    const int blocks = (N / 16) * S;
     hipLaunchKernelGGL((gemm_bf16_stream<MT, 8 / (MT > 2 ? 2 : 1)>), dim3(blocks), dim3(256), 0, st,
                        (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per);
 }
@@ -306,8 +320,7 @@ static void launch_attn(sd_session *s, const T *q, const T *k, const T *v, T *ou
                         hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
     const int s_cap = (int)align_up(pos0 + n_new, 64);
-    constexpr int NG = 256 / (D / 2);
-    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)NG * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D>),

@@ -21,13 +21,16 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 template <int MT, int UNROLL>
 __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
                                                        float *__restrict__ part, int M, int Mpad, int N, int K,
-                                                       int S, int ks_per) {
-    const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                       int SB, int ks_per_blk) {
+    // One workgroup = one 16-column n-tile x one k-slab; its 4 waves take a quarter of the slab each and fold
+    // their accumulators through LDS, so the number of partial slabs in HBM is SB, not 4*SB.
+    __shared__ f32x4 red[4][MT][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int NTL = N >> 4, KS = K >> 5;
-    if (unit >= NTL * S) return;
-    const int s = unit / NTL, nt = unit - s * NTL;
-    const int ks0 = s * ks_per, ks1 = min(KS, ks0 + ks_per);
+    const int sb = blockIdx.x / NTL, nt = blockIdx.x - sb * NTL;
+    const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
+    const int per = (kb1 - kb0 + 3) >> 2;
+    const int ks0 = min(kb1, kb0 + wv * per), ks1 = min(kb1, ks0 + per);
     const u32x4 *wp = Wp + ((size_t)nt * KS + ks0) * 64 + lane;
     const int mrow = lane & 15, kq = (lane >> 4) * 8;
     const bf16_t *xp[MT];
@@ -74,11 +77,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         }
         wp += 64;
     }
-    const int n = nt * 16 + (lane >> 4) * 4;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-        if (mv[t])
-            *reinterpret_cast<f32x4 *>(part + ((size_t)s * Mpad + t * 16 + mrow) * N + n) = acc[t];
+    for (int t = 0; t < MT; ++t) red[wv][t][lane] = acc[t];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
+        const int t = idx >> 6, l = idx & 63;
+        const int m = t * 16 + (l & 15);
+        if (m < M) {
+            const f32x4 r = (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]);
+            *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = r;
+        }
+    }
 }
 
 // fp32 storage (parity runs on small models): one wave per output column, lanes stride K.
@@ -341,9 +350,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, c
                                                   float inv_sqrt_d, int s_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
-    float *red = qs + ATT_TQ * D;                                 // [NG][TQ][D]
-    constexpr int HD = D / 2, NG = 256 / HD;
-    float *sc = red + NG * ATT_TQ * D;                            // [TQ][s_cap]
+    float *red = qs + ATT_TQ * D;                                 // [4 waves][TQ][D]
+    float *sc = red + 4 * ATT_TQ * D;                             // [TQ][s_cap]
     const int head = blockIdx.x, r0 = blockIdx.y * ATT_TQ;
     const int nr = min(ATT_TQ, n_new - r0);
     const int kvh = head / (Hq / Hkv);
@@ -444,30 +452,48 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, c
     __syncthreads();
 
     {
-        const int dp = tid % HD, sg = tid / HD;
-        float a0[ATT_TQ], a1[ATT_TQ];
+        // P.V: 16-byte V loads, LPR lanes across one key row, the other lanes of the wave on other keys; keys
+        // striped over all thread groups; partial sums folded inside the wave by shuffles, then across the 4
+        // waves through LDS.
+        constexpr int LPR = D / 8, GPW = 64 / LPR, NGRP = 256 / LPR;
+        const int dp = tid % LPR, sg = tid / LPR;
+        float a[ATT_TQ][8];
 #pragma unroll
-        for (int t = 0; t < ATT_TQ; ++t) a0[t] = a1[t] = 0.f;
-        for (int s = sg; s < s_hi; s += NG) {
-            const float v0 = to_f(Vv[(size_t)s * D + 2 * dp]), v1 = to_f(Vv[(size_t)s * D + 2 * dp + 1]);
+        for (int t = 0; t < ATT_TQ; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[t][j] = 0.f;
+#pragma unroll 4
+        for (int s = sg; s < s_hi; s += NGRP) {
+            float v[8];
+            load8(Vv + (size_t)s * D + dp * 8, v);
 #pragma unroll
             for (int t = 0; t < ATT_TQ; ++t) {
                 const float p = sc[(size_t)t * s_cap + s];
-                a0[t] = fmaf(p, v0, a0[t]);
-                a1[t] = fmaf(p, v1, a1[t]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
             }
         }
 #pragma unroll
-        for (int t = 0; t < ATT_TQ; ++t) {
-            red[((size_t)sg * ATT_TQ + t) * D + 2 * dp] = a0[t];
-            red[((size_t)sg * ATT_TQ + t) * D + 2 * dp + 1] = a1[t];
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int t = 0; t < ATT_TQ; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[t][j] += __shfl_xor(a[t][j], off, 64);
+        const int w = tid >> 6, lane = tid & 63;
+        if (lane < LPR) {
+#pragma unroll
+            for (int t = 0; t < ATT_TQ; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[((size_t)w * ATT_TQ + t) * D + lane * 8 + j] = a[t][j];
         }
+        (void)GPW;
     }
     __syncthreads();
     for (int i = tid; i < nr * D; i += 256) {
         const int t = i / D, d = i - t * D;
         float a = 0.f;
-        for (int g = 0; g < NG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
         out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a);
     }
 }

@@ -108,26 +108,54 @@ struct NormShared {
     float redf[16];
     int redi[16];
     double redd[16];
+    uint32_t redu[16];
     int n_cand;
     int cut_idx;
     uint32_t cut_key;
     int kept;
+    float lse;
+    int tok;
     uint32_t ckey[MAX_CAND];
     int cidx[MAX_CAND];
     uint32_t skey[MAX_CAND];
     int sidx[MAX_CAND];
 };
 
+// Stable descending order of the n (<= MAX_CAND) candidates in ckey/cidx by rank counting -> skey/sidx.
+__device__ __forceinline__ void rank_sort(NormShared &S, int n) {
+    const int tid = threadIdx.x;
+    if (tid < n) {
+        const uint32_t k = S.ckey[tid];
+        const int id = S.cidx[tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t kj = S.ckey[j];
+            rank += (kj > k) || (kj == k && S.cidx[j] < id);
+        }
+        S.skey[rank] = k;
+        S.sidx[rank] = id;
+    }
+    __syncthreads();
+}
+
+// norm_logits (+ optionally the sample that follows it in the draft / autoregressive loops, utils.py:213-233).
+// Fast path (1 <= top_k <= 64, the harness runs k = 20): three passes over the row - stage, compact, write -
+// and everything else on a candidate list of a few dozen entries in LDS.  Any other setting takes the general
+// path (bitwise bisection on the ordered key for top-k, mass bisection for a wide top-p).
+template <bool SAMPLE>
 __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict__ logits, long ld_in, int V,
                                                        float temperature, int top_k, float top_p, int bf16_round,
                                                        int staged, float *__restrict__ out, long ld_out,
-                                                       int *__restrict__ err) {
+                                                       int *__restrict__ err, const float *__restrict__ noise,
+                                                       uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
+                                                       int *__restrict__ samp_err) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NormShared &S = *reinterpret_cast<NormShared *>(smem);
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *x = logits + (size_t)row * ld_in;
     float *o = out + (size_t)row * ld_out;
+    const uint32_t neg_inf_key = 0x007fffffu;                     // fkey(-inf)
 
     auto load_z = [&](int i) -> float {
         float v = x[i];
@@ -136,108 +164,170 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     };
     auto Z = [&](int i) -> float { return staged ? zs[i] : load_z(i); };
 
-    // pass 0: stage, row max, NaN detection
-    float m = -INFINITY;
+    // pass 0: stage, row max, NaN detection (16-byte loads, all of a thread's loads in flight at once)
+    float mt = -INFINITY;
     int bad = 0;
-    for (int i = tid; i < V; i += NT) {
-        const float z = load_z(i);
-        if (staged) zs[i] = z;
-        bad |= (z != z);
-        m = fmaxf(m, z);
+    if (staged && (V & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        const int V4 = V >> 2;
+        for (int i0 = tid; i0 < V4; i0 += NT * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = i0 + u * NT;
+                if (i4 < V4) v[u] = reinterpret_cast<const float4 *>(x)[i4];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = i0 + u * NT;
+                if (i4 < V4) {
+                    float4 z = v[u];
+                    if (bf16_round) {
+                        z.x = (float)(bf16_t)z.x; z.y = (float)(bf16_t)z.y; z.z = (float)(bf16_t)z.z; z.w = (float)(bf16_t)z.w;
+                    }
+                    z.x = z.x / temperature; z.y = z.y / temperature; z.z = z.z / temperature; z.w = z.w / temperature;
+                    reinterpret_cast<float4 *>(zs)[i4] = z;
+                    bad |= (z.x != z.x) | (z.y != z.y) | (z.z != z.z) | (z.w != z.w);
+                    mt = fmaxf(fmaxf(mt, fmaxf(z.x, z.y)), fmaxf(z.z, z.w));
+                }
+            }
+        }
+        __syncthreads();                                          // (any partition of the row works for the prefilter)
+    } else {
+        for (int i = tid; i < V; i += NT) {
+            const float z = load_z(i);
+            if (staged) zs[i] = z;
+            bad |= (z != z);
+            mt = fmaxf(mt, z);
+        }
     }
-    m = block_max(m, S.redf);
+    const float m = block_max(mt, S.redf);
     bad = block_sum_i(bad, S.redi);
     if (bad || m == INFINITY || m == -INFINITY) {                 // exp(log_softmax) would hold NaN (utils.py:203)
         for (int i = tid; i < V; i += NT) o[i] = __uint_as_float(0x7fc00000u);
-        if (tid == 0 && err) err[row] = 1;
+        if (tid == 0) {
+            if (err) err[row] = 1;
+            if (SAMPLE && samp_err) *samp_err = 1;
+        }
         return;
     }
 
-    // top-k (utils.py:166-169): the k-th largest value by bitwise bisection on the ordered key;
-    // everything strictly below it is dropped, ties at the k-th value stay.
     uint32_t kth = 0u;                                            // key >= 0 keeps everything
-    int n_surv = V;
+    bool have_list = false;                                       // skey/sidx hold a superset of the survivors, sorted
+    int n_list = 0, n_surv = V;
     if (top_k > 0) {
         const int k = min(top_k, V);
-        uint32_t prefix = 0u;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t cand = prefix | (1u << bit);
-            int c = 0;
-            for (int i = tid; i < V; i += NT) c += (fkey(Z(i)) >= cand);
-            c = block_sum_i(c, S.redi);
-            if (c >= k) prefix = cand;
+        if (k <= 64) {
+            // ---- prefilter: a threshold t0 with at least k elements above it.  Each wave takes the k-th
+            // largest of its 64 per-thread maxima (rank counting over readlanes); t0 = the largest of those.
+            const uint32_t mk = fkey(mt);
+            int rank = 0;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const uint32_t kj = (uint32_t)__shfl((int)mk, j, 64);
+                rank += (kj > mk) || (kj == mk && j < lane);
+            }
+            const unsigned long long hit = __ballot(rank == k - 1);
+            const uint32_t wk = (uint32_t)__shfl((int)mk, hit ? (int)(__ffsll((long long)hit) - 1) : 0, 64);
+            __syncthreads();
+            if (lane == 0) S.redu[wv] = wk;
+            if (tid == 0) S.n_cand = 0;
+            __syncthreads();
+            uint32_t t0 = S.redu[0];
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) t0 = max(t0, S.redu[i]);
+            for (int i = tid; i < V; i += NT) {
+                const uint32_t kk = fkey(Z(i));
+                if (kk >= t0) {
+                    const int slot = atomicAdd(&S.n_cand, 1);
+                    if (slot < MAX_CAND) { S.ckey[slot] = kk; S.cidx[slot] = i; }
+                }
+            }
+            __syncthreads();
+            const int n = S.n_cand;
+            if (n <= MAX_CAND) {                                  // else: pathological ties, take the general path
+                rank_sort(S, n);
+                kth = S.skey[k - 1];                              // exact k-th largest value (t0 <= kth by construction)
+                int ns = k;
+                while (ns < n && S.skey[ns] == kth) ++ns;         // ties at the k-th value stay (utils.py:169)
+                n_surv = ns;
+                n_list = n;
+                have_list = true;
+            }
         }
-        kth = prefix;
-        int c = 0;
-        for (int i = tid; i < V; i += NT) c += (fkey(Z(i)) >= kth);
-        n_surv = block_sum_i(c, S.redi);
+        if (!have_list) {
+            // general top-k: bitwise bisection on the ordered key
+            uint32_t prefix = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = prefix | (1u << bit);
+                int c = 0;
+                for (int i = tid; i < V; i += NT) c += (fkey(Z(i)) >= cand);
+                c = block_sum_i(c, S.redi);
+                if (c >= k) prefix = cand;
+            }
+            kth = prefix;
+        }
     }
 
     // top-p (utils.py:170-178).  keep(i) <=> key_i > cut_key || (key_i == cut_key && i <= cut_idx)
     uint32_t cut_key = kth;
     int cut_idx = 0x7fffffff;
+    int kept = -1;                                                // >= 0: the kept set is skey/sidx[0..kept)
+    if (have_list) kept = n_surv;
     if (top_p > 0.0f) {
-        // softmax denominator over the survivors (the -inf entries add exp(-inf) = 0)
-        float part = 0.f;
-        for (int i = tid; i < V; i += NT) {
-            const float z = Z(i);
-            if (fkey(z) >= kth) part += expf(z - m);
-        }
-        const float denom = block_sum(part, S.redf);
-        const uint32_t neg_inf_key = fkey(-INFINITY);
-        // entries that are already -inf carry no mass and sort last; leave them out of the candidates
-        int c = 0;
-        for (int i = tid; i < V; i += NT) {
-            const uint32_t k = fkey(Z(i));
-            c += (k >= kth && k > neg_inf_key);
-        }
-        const int n_fin = block_sum_i(c, S.redi);
-        if (n_fin <= MAX_CAND) {
-            if (tid == 0) S.n_cand = 0;
-            __syncthreads();
+        if (!have_list) {
+            int c = 0;
             for (int i = tid; i < V; i += NT) {
-                const uint32_t k = fkey(Z(i));
-                if (k >= kth && k > neg_inf_key) {
-                    const int s = atomicAdd(&S.n_cand, 1);
-                    S.ckey[s] = k;
-                    S.cidx[s] = i;
-                }
+                const uint32_t kk = fkey(Z(i));
+                c += (kk >= kth && kk > neg_inf_key);
             }
-            __syncthreads();
-            const int n = S.n_cand;
-            if (tid < n) {                                        // stable descending order by rank counting
-                const uint32_t k = S.ckey[tid];
-                const int id = S.cidx[tid];
-                int rank = 0;
-                for (int j = 0; j < n; ++j) {
-                    const uint32_t kj = S.ckey[j];
-                    rank += (kj > k) || (kj == k && S.cidx[j] < id);
+            const int n_fin = block_sum_i(c, S.redi);
+            if (n_fin <= MAX_CAND) {
+                __syncthreads();
+                if (tid == 0) S.n_cand = 0;
+                __syncthreads();
+                for (int i = tid; i < V; i += NT) {
+                    const uint32_t kk = fkey(Z(i));
+                    if (kk >= kth && kk > neg_inf_key) {
+                        const int slot = atomicAdd(&S.n_cand, 1);
+                        S.ckey[slot] = kk;
+                        S.cidx[slot] = i;
+                    }
                 }
-                S.skey[rank] = k;
-                S.sidx[rank] = id;
+                __syncthreads();
+                rank_sort(S, S.n_cand);
+                n_surv = S.n_cand;
+                have_list = true;
             }
-            __syncthreads();
+        }
+        if (have_list) {
             if (tid == 0) {
+                // entries that are already -inf carry no mass and sort last: leave them out
+                int nf = n_surv;
+                while (nf > 1 && S.skey[nf - 1] <= neg_inf_key) --nf;
+                float denom = 0.f;                                // softmax denominator over the survivors
+                for (int i = 0; i < nf; ++i) denom += expf(Z(S.sidx[i]) - m);
                 // torch.cumsum accumulates float32 inputs in double and rounds each prefix to float32
                 double cum = 0.0;
-                int kept = 0;
-                for (int i = 0; i < n; ++i) {
+                int kp = 0;
+                for (int i = 0; i < nf; ++i) {
                     if (i > 0 && (float)cum > top_p) break;       // shifted filter: the crossing token stays
-                    const float p = expf(Z(S.sidx[i]) - m) / denom;
-                    cum += (double)p;
-                    kept = i + 1;
+                    cum += (double)(expf(Z(S.sidx[i]) - m) / denom);
+                    kp = i + 1;
                 }
-                S.kept = kept;
-                S.cut_key = S.skey[kept - 1];
-                S.cut_idx = S.sidx[kept - 1];
+                S.kept = kp;
             }
             __syncthreads();
-            cut_key = S.cut_key;
-            cut_idx = S.cut_idx;
+            kept = S.kept;
         } else {
-            // General path (no / very wide top-k): smallest existing value v* whose first tie member is
-            // kept, i.e. float(mass strictly above v*) <= top_p, by bisection on the key; then how many
-            // of its tie members fit.  Mass is accumulated in double like torch.cumsum does.
+            // General path (no / very wide top-k): smallest existing value v* whose first tie member is kept,
+            // i.e. float(mass strictly above v*) <= top_p, by bisection on the key; then how many of its tie
+            // members fit.  Mass is accumulated in double like torch.cumsum does.
+            float part = 0.f;
+            for (int i = tid; i < V; i += NT) {
+                const float z = Z(i);
+                if (fkey(z) >= kth) part += expf(z - m);
+            }
+            const float denom = block_sum(part, S.redf);
             uint32_t lo = (kth > neg_inf_key + 1u) ? kth : neg_inf_key + 1u, hi = fkey(m);
             while (lo < hi) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -249,35 +339,27 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 g = block_sum_d(g, S.redd);
                 if (!((float)g > top_p)) hi = mid; else lo = mid + 1u;
             }
-            // v* = smallest existing key >= lo
-            uint32_t best = 0xffffffffu;
+            uint32_t best = 0xffffffffu;                          // v* = smallest existing key >= lo
             for (int i = tid; i < V; i += NT) {
-                const uint32_t k = fkey(Z(i));
-                if (k >= lo) best = min(best, k);
+                const uint32_t kk = fkey(Z(i));
+                if (kk >= lo) best = min(best, kk);
             }
-            {
-                int b = (int)(best ^ 0x80000000u);                // order-preserving map to signed for the int reduce
-                __syncthreads();
-                // block min through LDS
-                const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
-                for (int of = 32; of > 0; of >>= 1) b = min(b, __shfl_xor(b, of, 64));
-                if (lane == 0) S.redi[w] = b;
-                __syncthreads();
-                int r = S.redi[0];
-                for (int i2 = 1; i2 < NT / 64; ++i2) r = min(r, S.redi[i2]);
-                best = (uint32_t)r ^ 0x80000000u;
-                __syncthreads();
-            }
+            for (int of = 32; of > 0; of >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, of, 64));
+            __syncthreads();
+            if (lane == 0) S.redu[wv] = best;
+            __syncthreads();
+            best = S.redu[0];
+            for (int i2 = 1; i2 < NT / 64; ++i2) best = min(best, S.redu[i2]);
             const uint32_t vstar = best;
             double g = 0.0;
             int e = 0;
             float pv = 0.f;
             for (int i = tid; i < V; i += NT) {
                 const float z = Z(i);
-                const uint32_t k = fkey(z);
-                if (k > vstar) g += (double)(expf(z - m) / denom);
-                if (k == vstar) { e += 1; pv = expf(z - m) / denom; }
+                const uint32_t kk = fkey(z);
+                if (kk > vstar) g += (double)(expf(z - m) / denom);
+                if (kk == vstar) { e += 1; pv = expf(z - m) / denom; }
             }
             g = block_sum_d(g, S.redd);
             e = block_sum_i(e, S.redi);
@@ -303,22 +385,77 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
     }
 
-    // probs = exp(log_softmax(filtered))  (utils.py:199)
-    float part = 0.f;
-    for (int i = tid; i < V; i += NT) {
-        const float z = Z(i);
-        const uint32_t k = fkey(z);
-        if (k > cut_key || (k == cut_key && i <= cut_idx)) part += expf(z - m);
-    }
-    const float lse = logf(block_sum(part, S.redf));
-    for (int i = tid; i < V; i += NT) {
-        const float z = Z(i);
-        const uint32_t k = fkey(z);
-        const bool keep = k > cut_key || (k == cut_key && i <= cut_idx);
-        o[i] = keep ? expf((z - m) - lse) : 0.0f;
+    // probs = exp(log_softmax(filtered))  (utils.py:199), then optionally sample (utils.py:213-233)
+    if (kept >= 0) {
+        // list mode: the kept set is the first `kept` entries of the sorted candidate list
+        if (tid == 0) {
+            float sum = 0.f;
+            for (int i = 0; i < kept; ++i) sum += expf(Z(S.sidx[i]) - m);
+            S.lse = logf(sum);
+        }
+        if ((V & 3) == 0 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+            for (int i4 = tid; i4 < (V >> 2); i4 += NT) reinterpret_cast<float4 *>(o)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int i = tid; i < V; i += NT) o[i] = 0.0f;
+        }
+        __syncthreads();
+        const float lse = S.lse;
+        if (tid < kept) o[S.sidx[tid]] = expf((Z(S.sidx[tid]) - m) - lse);
+        if (SAMPLE && tid == 0) {
+            // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and
+            // never win); first index wins ties; fix-up for a pick below 1e-9 (utils.py:228-230)
+            float best = -1.f;
+            int bi = 0x7fffffff;
+            float pbest = 0.f;
+            for (int i = 0; i < kept; ++i) {
+                const int id = S.sidx[i];
+                const float p = expf((Z(id) - m) - lse);
+                if (!(p > 0.f)) continue;
+                const float e = noise ? noise[id] : philox_exp(seed, draw, id);
+                const float r = p / e;
+                if (r > best || (r == best && id < bi)) { best = r; bi = id; pbest = p; }
+            }
+            if (pbest < 1e-9f) bi = S.sidx[0];                    // argmax(probs): list head (lowest index among ties)
+            *tok_out = bi;
+            if (samp_err) *samp_err = 0;
+        }
+    } else {
+        float part = 0.f;
+        for (int i = tid; i < V; i += NT) {
+            const float z = Z(i);
+            const uint32_t kk = fkey(z);
+            if (kk > cut_key || (kk == cut_key && i <= cut_idx)) part += expf(z - m);
+        }
+        const float lse = logf(block_sum(part, S.redf));
+        auto P = [&](int i) -> float {
+            const float z = Z(i);
+            const uint32_t kk = fkey(z);
+            const bool keep = kk > cut_key || (kk == cut_key && i <= cut_idx);
+            return keep ? expf((z - m) - lse) : 0.0f;
+        };
+        for (int i = tid; i < V; i += NT) o[i] = P(i);
+        if (SAMPLE) {
+            ArgMax br = {0.f, 0x7fffffff}, bw = {0.f, 0x7fffffff};
+            for (int i = tid; i < V; i += NT) {
+                const float p = P(i);
+                if (!(p > 0.f)) continue;
+                const float r = p / (noise ? noise[i] : philox_exp(seed, draw, i));
+                if (br.i == 0x7fffffff || r > br.v) br = {r, i};
+                if (bw.i == 0x7fffffff || p > bw.v) bw = {p, i};
+            }
+            ArgMax *sha = reinterpret_cast<ArgMax *>(S.ckey);
+            br = block_argmax(br, sha);
+            bw = block_argmax(bw, sha);
+            if (tid == 0) {
+                int tok = br.i;
+                if (P(tok) < 1e-9f) tok = bw.i;
+                *tok_out = tok;
+                if (samp_err) *samp_err = 0;
+            }
+        }
     }
     if (tid == 0 && err) err[row] = 0;
-    (void)n_surv;
+    (void)n_list;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,7 +477,7 @@ __device__ __forceinline__ int sample_core(int V, WF W, EF E, SampleShared &S, i
         const float w = W(i);
         bad |= !(w >= 0.0f) || (w == INFINITY);                   // negative, NaN or Inf: multinomial's validity check
         pos |= (w > 0.0f);
-        const float r = w / E(i);                                 // IEEE division, as at::div
+        const float r = w > 0.0f ? w / E(i) : 0.0f;               // IEEE division, as at::div; 0/e = 0 needs no variate
         if (best_r.i == 0x7fffffff || r > best_r.v) best_r = {r, i};
         if (best_w.i == 0x7fffffff || w > best_w.v) best_w = {w, i};
     }
@@ -464,25 +601,50 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                       int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
+                       const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *stream) {
+    const int staged = V <= LDS_ROW_LIMIT;
+    const size_t base = (sizeof(NormShared) + 15) & ~size_t(15);
+    const size_t lds = base + (staged ? (size_t)V * sizeof(float) : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(norm_probs_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(norm_probs_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (do_sample)
+        hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
+                           temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
+                           seed, draw, tok_out, samp_err);
+    else
+        hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
+                           temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
+                           (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
 extern "C" int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
                              float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
                              void *stream) {
     SD_REQUIRE(logits && probs_out && rows >= 0 && V > 0, "sd_norm_probs: bad arguments");
     SD_REQUIRE(temperature != 0.0f, "sd_norm_probs: temperature must be non-zero");
     if (rows == 0) return SD_OK;
-    const int staged = V <= LDS_ROW_LIMIT;
-    const size_t base = (sizeof(NormShared) + 15) & ~size_t(15);
-    const size_t lds = base + (staged ? (size_t)V * sizeof(float) : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(norm_probs_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(norm_probs_kernel, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
-                       temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag);
-    SD_LAUNCH_CHECK();
-    return SD_OK;
+    return launch_norm(logits, rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, probs_out, ld_out,
+                       err_flag, false, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
+                              int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
+                              uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err,
+                              void *stream) {
+    SD_REQUIRE(logits && probs_out && tok_out && V > 0, "sd_norm_sample: bad arguments");
+    SD_REQUIRE(temperature != 0.0f, "sd_norm_sample: temperature must be non-zero");
+    return launch_norm(logits, 1, V, V, temperature, top_k, top_p, bf16_round_logits, probs_out, V, err_flag, true,
+                       exp_noise, philox_seed, draw_index, tok_out, sample_err, stream);
 }
 
 extern "C" int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,

@@ -35,15 +35,7 @@ def autoregressive_sampling(x: torch.Tensor, model, N: int, eos_token_id: int, t
     # the EOS test needs each token on the host (autoregressive_sampling.py:55): one 4-byte read per step
     for i in range(N):
         S = L0 + i
-        kv.forward_rows(seq32, S, 1)
-        row = kv._probs[S - 1]
-        if noise.on_device:
-            check(lib.sd_sample(row.data_ptr(), V, None, noise.seed, noise.next_draws(1), seq32[S].data_ptr(),
-                                err.data_ptr(), st), "sd_sample")
-        else:
-            e = noise.exponential(V)
-            check(lib.sd_sample(row.data_ptr(), V, e.data_ptr(), 0, 0, seq32[S].data_ptr(), err.data_ptr(), st),
-                  "sd_sample")
+        kv.forward_sample(seq32, S, noise, err)
         n_out += 1
         tok = int(seq32[S])
         if int(err) != 0:

@@ -108,6 +108,39 @@ class KVCacheModel:
             self._hist_lo = first
         self._hist_len = upto
 
+    def forward_sample(self, seq32: torch.Tensor, upto: int, noise, samp_err: torch.Tensor) -> None:
+        """One draft / autoregressive step: feed seq32[cache_len:upto], normalise the last row into the arena
+        and sample the next token straight into seq32[upto] (one fused launch after the forward)."""
+        ses = self._session
+        t0 = process_time_ns()
+        ev0 = None
+        n_new = upto - ses.cache_len
+        if self.event_log is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        logits = ses.forward(seq32[ses.cache_len:upto], 1)
+        t1 = process_time_ns()
+        V = self._model.cfg.vocab_size
+        row = upto - 1
+        if noise.on_device:
+            e_ptr, seed, draw = None, noise.seed, noise.next_draws(1)
+        else:
+            e = noise.exponential(V)
+            e_ptr, seed, draw = e.data_ptr(), 0, 0
+        check(lib.sd_norm_sample(logits.data_ptr(), V, float(self._temperature), int(self._top_k or 0),
+                                 float(self._top_p or 0.0), 0, self._probs[row].data_ptr(), self._err[row].data_ptr(),
+                                 e_ptr, seed, draw, seq32[upto].data_ptr(), samp_err.data_ptr(), _stream()),
+              "sd_norm_sample")
+        self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
+        self.forward_time_dict["_model_time"] += t1 - t0
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            self.event_log.append((ev0, ev1, n_new, upto))
+        if self._hist_len == 0:
+            self._hist_lo = row
+        self._hist_len = upto
+
     def check_errors(self, lo: int, hi: int) -> None:
         if bool(self._err[lo:hi].any()):
             raise RuntimeError("norm logits error")       # reference utils.py:207

@@ -82,15 +82,7 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
             L = len(host_seq)
             # ---- draft: gamma steps, tokens never leave the device (kvcache_model.py:279-293)
             for i in range(gamma):
-                draft.forward_rows(seq32, L + i, 1)
-                row = q_hist[L + i - 1]
-                if noise.on_device:
-                    check(lib.sd_sample(row.data_ptr(), V, None, noise.seed, noise.next_draws(1),
-                                        seq32[L + i].data_ptr(), serr[i].data_ptr(), st), "sd_sample")
-                else:
-                    e = noise.exponential(V)
-                    check(lib.sd_sample(row.data_ptr(), V, e.data_ptr(), 0, 0, seq32[L + i].data_ptr(),
-                                        serr[i].data_ptr(), st), "sd_sample")
+                draft.forward_sample(seq32, L + i, noise, serr[i])
             approx_calls += 1
             approx_time += process_time_ns() - tick
             tick = process_time_ns()

@@ -354,3 +354,47 @@ def test_batch_size_assert(hip):
     m = hip.engine.SpecDecModel.from_state_dict(cfg, make_state_dict(cfg, 21), dtype=torch.float32)
     with pytest.raises(AssertionError, match="input batch size must be 1"):
         hip.S.speculative_sampling(torch.ones(2, 4, dtype=torch.int64).cuda(), m, m, 2, None, 4)
+
+
+# --------------------------------------------------------------------------- kernel-level checks
+@pytest.mark.parametrize("N,K", [(2304, 768), (5120, 13824), (32000, 768), (1024, 5120)])
+def test_gemm_bf16_stream_vs_fp32_reference(hip, N, K):
+    """The MFMA weight-streaming GEMM (tile-packed bf16 weights, split-K partials) against a plain PyTorch fp32
+    matmul of the same bf16-rounded operands; fp32 accumulation both sides, so only the summation order differs."""
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    Wp = torch.empty_like(W)
+    hip.L.check(hip.lib.sd_pack_weight_bf16(W.data_ptr(), Wp.data_ptr(), N, K, _st()))
+    # the packed layout is a pure permutation of 16x32 tiles
+    ref_pack = W.view(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+    assert torch.equal(Wp, ref_pack)
+    part = torch.empty(64 * 64 * N, dtype=torch.float32, device="cuda")
+    for M in (1, 5, 16, 17, 33, 64):
+        x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        S = C.c_int(0)
+        hip.L.check(hip.lib.sd_gemm_bf16(Wp.data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(),
+                                         out.data_ptr(), C.byref(S), _st()))
+        ref = x.float() @ W.float().t()
+        err = float((out - ref).abs().max())
+        assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, (M, N, K, S.value, err)
+
+
+def test_norm_sample_fused_matches_two_step(hip):
+    """sd_norm_sample == norm_logits followed by sample on the same noise, for the fast (k <= 64) and general paths."""
+    for V, (T, k, p) in [(32000, (1.0, 20, 0.9)), (32000, (0.7, 50, 0.95)), (50272, (1.0, 20, 0.9)),
+                         (4096, (1.0, 0, 0.9)), (4096, (1.0, 200, 0.0)), (512, (1.0, 0, 0.0)), (32000, (1.0, 1, 0.0))]:
+        for i in range(4):
+            x = logits_row(8800 + i, V, 3.0).cuda()
+            noise = torch.empty(V).exponential_(1).cuda()
+            probs = hip.S.norm_logits(x, T, k, p)
+            want = hip.S.sample(probs, noise=hip.noise.ReplayNoise([("exp", noise.cpu())], "cuda"))
+            out = torch.empty(V, dtype=torch.float32, device="cuda")
+            tok = torch.zeros(1, dtype=torch.int32, device="cuda")
+            err = torch.zeros(2, dtype=torch.int32, device="cuda")
+            hip.L.check(hip.lib.sd_norm_sample(x.data_ptr(), V, T, k, p, 0, out.data_ptr(), err[0].data_ptr(),
+                                               noise.data_ptr(), 0, 0, tok.data_ptr(), err[1].data_ptr(), _st()))
+            assert torch.equal(out, probs[0])
+            assert int(tok) == int(want) and not bool(err.any())
+            ref = oracle.sample(oracle.norm_logits(x.cpu(), T, k, p), oracle.RecordedNoise([("exp", noise.cpu()[None])]))
+            assert int(tok) == int(ref)

@@ -55,7 +55,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["qkv", "o", "gate_up", "down", "lm_head"]
     for n in which:
         N, K = SHAPES[n]
-        for u in (None, 1024, 2048, 3072, 6144, 8192, 16384):
+        for u in (None, 512, 768, 1024, 1280, 2048, 2560, 4096):
             bench(n, N, K, units=u)
     for M in (1, 2, 5, 16, 32, 64):
         bench("gate_up", *SHAPES["gate_up"], M=M)
