@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--rng", default="device", choices=["device", "host"],
                     help="device = on-device Philox (throughput mode); host = torch CPU generator in the reference's order")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on a bounded sample (rank 0, N=1)")
-    ap.add_argument("--cpu-max-len", type=int, default=6)
+    ap.add_argument("--cpu-max-len", type=int, default=16)
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="wall budget for the CPU baseline runs")
     ap.add_argument("--cpu-prompt-len", type=int, default=128)
     ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
     return ap.parse_args()
@@ -62,11 +63,36 @@ def prompt_for(stream, V, L):
     return torch.randint(3, V, (1, L), generator=g)
 
 
+def host_cpu_share():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box exposes
+    256 hardware threads but grants a 16-core share per GPU; oversubscribing torch's pool stalls it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("SPECDEC_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 16 if not env else n))
+
+
 def cpu_baseline(args, dcfg, tcfg, dm, tm):
     """The oracle (torch-CPU restatement, pinned to the reference by tests/golden) on the host cores,
-    same weights, same dtype, a bounded sample of the same workload."""
+    same weights, same dtype, a bounded sample of the same workload: same prompt length, fewer new tokens.
+    Runs grow (max_len 1, then as many as the time budget allows) so a slow host still yields a number."""
     import oracle
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    ncores = host_cpu_share()
     torch.set_num_threads(ncores)
     t0 = time.time()
     dsd = {n: dm._synth_get(n).cpu() for n in dm._synth_names}
@@ -75,24 +101,52 @@ def cpu_baseline(args, dcfg, tcfg, dm, tm):
         if "model.decoder.embed_tokens.weight" in sd:
             sd["lm_head.weight"] = sd["model.decoder.embed_tokens.weight"]
     t_copy = time.time() - t0
+    print(f"[cpu_baseline] weights on host in {t_copy:.1f} s, {ncores} threads", file=sys.stderr, flush=True)
     od, ot = oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd)
     prompt = prompt_for(0, tcfg.vocab_size, args.cpu_prompt_len)
-    torch.manual_seed(2000)
-    w0, p0 = time.time(), time.process_time()
-    out, d = oracle.speculative_sampling(prompt, od, ot, 2, None, args.cpu_max_len, gamma=args.gamma,
-                                         top_k=args.top_k, top_p=args.top_p, details=True)
-    wall, cpu = time.time() - w0, time.process_time() - p0
-    new = int(out.shape[1] - prompt.shape[1])
-    iters = d["target_call_times"]
-    # split: first iteration carries both prefills
+    best = None
+    n_tok = 1
+    budget = float(args.cpu_budget_s)
+    spent = 0.0
+    while True:
+        torch.manual_seed(2000)
+        w0, p0 = time.time(), time.process_time()
+        out, d = oracle.speculative_sampling(prompt, od, ot, 2, None, n_tok, gamma=args.gamma,
+                                             top_k=args.top_k, top_p=args.top_p, details=True)
+        wall, cpu = time.time() - w0, time.process_time() - p0
+        spent += wall
+        new = int(out.shape[1] - prompt.shape[1])
+        iters = d["target_call_times"]
+        print(f"[cpu_baseline] max_len {n_tok}: {new} tokens, {iters} iterations, {wall:.1f} s wall", file=sys.stderr, flush=True)
+        run = dict(n_tok=n_tok, new=new, iters=iters, wall=wall, cpu=cpu, acc=d["acc_len"])
+        if best is not None and iters > best["iters"]:
+            per_iter = (wall - best["wall"]) / max(1, iters - best["iters"])
+        else:
+            per_iter = None
+        run["per_iter"] = per_iter
+        best = run
+        if per_iter is None:
+            nxt = n_tok + 2
+            est = wall * 1.3
+        else:
+            room = budget - spent
+            more = int(max(0.0, room - (wall - per_iter * iters)) / max(per_iter, 1e-3))
+            nxt = min(args.cpu_max_len, more)
+            est = (wall - per_iter * iters) + per_iter * nxt
+        if nxt <= n_tok or spent + est > budget or n_tok >= args.cpu_max_len:
+            break
+        n_tok = nxt
+    r = best
+    per_iter_txt = f"{r['per_iter']:.2f} s per draft+verify iteration after the prefill; " if r["per_iter"] else ""
     return {
-        "value": new / wall, "unit": "tokens/s", "cores": ncores, "kind": "port",
-        "sample": (f"oracle.speculative_sampling, same random-init bf16 weights copied from the GPU, prompt "
-                   f"{args.cpu_prompt_len}, max_len {args.cpu_max_len} (vs {args.max_len} on the GPU), gamma {args.gamma}: "
-                   f"{new} tokens in {wall:.1f} s wall / {cpu:.1f} s process_time over {iters} iterations; "
-                   f"weight copy {t_copy:.1f} s not timed"),
-        "wall_s": wall, "process_time_s": cpu, "iterations": iters,
-        "mean_accept_len": float(np.mean(d["acc_len"])) if d["acc_len"] else 0.0,
+        "value": r["new"] / r["wall"], "unit": "tokens/s", "cores": ncores, "kind": "port",
+        "sample": (f"oracle.speculative_sampling (torch-CPU restatement), same random-init bf16 weights as the GPU run, "
+                   f"prompt {args.cpu_prompt_len}, max_len {r['n_tok']} (the GPU run uses max_len {args.max_len}), gamma "
+                   f"{args.gamma}: {r['new']} tokens in {r['wall']:.1f} s wall / {r['cpu']:.1f} s process_time over "
+                   f"{r['iters']} iterations incl. both prefills; {per_iter_txt}weight copy {t_copy:.1f} s not timed"),
+        "wall_s": r["wall"], "process_time_s": r["cpu"], "iterations": r["iters"],
+        "s_per_iteration": r["per_iter"],
+        "mean_accept_len": float(np.mean(r["acc"])) if r["acc"] else 0.0,
     }
 
 
@@ -155,12 +209,10 @@ def main():
         outs.append(out)
     if dist is not None:
         # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
+        from llmspeculativesampling_amd.dist import gather_streams
         width = args.prompt_len + args.max_len + args.gamma + 1
-        mine = torch.full((args.steps, width), -1, dtype=torch.int32, device="cuda")
-        for i, o in enumerate(outs):
-            mine[i, : o.shape[1]] = o[0].to(torch.int32)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+        all_streams = gather_streams(outs, args.steps * world, width, device="cuda")
+        assert len(all_streams) == args.steps * world
     barrier()
     elapsed = time.time() - t0
     stats = torch.tensor([elapsed, float(new_tokens), float(acc_sum), float(n_iters)], dtype=torch.float64, device="cuda")
