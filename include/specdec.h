@@ -118,12 +118,18 @@ typedef struct {
     int32_t opt_proj_dim;         /* OPT word_embed_proj_dim (== hidden when no project_in/out) */
     float norm_eps;
     int32_t logits_bf16_round;    /* round logits to bf16 before use (bf16 lm_head semantics)   */
+    int32_t fused_layout;         /* bf16 only: wqkv / w_gate_up rows are in the fused-epilogue order below      */
 } sd_model_config;
 
 /* Weight table.  Matrices are [out][in] as in nn.Linear.  For dtype SD_BF16 every GEMM matrix is
  * handed over in the tile-packed layout produced by sd_pack_weight_bf16 ("HBM
  * layout"); for SD_F32 they stay row-major.  Vectors / embeddings are row-major in `dtype`.
- * Per-layer arrays have n_layers entries.  Unused entries are NULL. */
+ * Per-layer arrays have n_layers entries.  Unused entries are NULL.
+ * With cfg.fused_layout (bf16): the QKV and gate/up GEMMs keep the whole k-range in one workgroup and finish with
+ * a fused epilogue (RoPE + in-place KV append; SiLU(gate)*up / ReLU), which needs two row orders prepared at load:
+ *   llama wqkv: inside each q and k head the rows are pair-interleaved, d0, d0+D/2, d1, d1+D/2, ... (v heads natural);
+ *   llama w_gate_up: 8 gate rows then the same 8 up rows, repeated: g0..g7,u0..u7,g8..g15,u8..u15,...
+ * OPT keeps the natural order. */
 typedef struct {
     const void *embed;            /* [vocab][embed_dim] row-major                               */
     const void *pos_embed;        /* OPT: [max_pos+2][hidden]                                   */

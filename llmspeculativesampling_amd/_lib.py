@@ -28,7 +28,8 @@ class SdModelConfig(C.Structure):
     _fields_ = [("arch", C.c_int32), ("dtype", C.c_int32), ("vocab", C.c_int32), ("hidden", C.c_int32),
                 ("inter", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
                 ("head_dim", C.c_int32), ("max_pos", C.c_int32), ("opt_pre_ln", C.c_int32),
-                ("opt_proj_dim", C.c_int32), ("norm_eps", C.c_float), ("logits_bf16_round", C.c_int32)]
+                ("opt_proj_dim", C.c_int32), ("norm_eps", C.c_float), ("logits_bf16_round", C.c_int32),
+                ("fused_layout", C.c_int32)]
 
 
 _VP = C.c_void_p

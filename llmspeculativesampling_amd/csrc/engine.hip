@@ -281,15 +281,26 @@ struct GemmOut {
     size_t stride_s;   // floats between k-slices
 };
 
-template <int MT>
+template <int MT, int EPI>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
-                             int ks_per, hipStream_t st) {
+                             int ks_per, const GemmEpi &e, hipStream_t st) {
     const int blocks = (N / 16) * S;
-    hipLaunchKernelGGL((gemm_bf16_stream<MT, 8 / (MT > 2 ? 2 : 1)>), dim3(blocks), dim3(256), 0, st,
-                       (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per);
+    hipLaunchKernelGGL((gemm_bf16_stream<MT, 8 / (MT > 2 ? 2 : 1), EPI>), dim3(blocks), dim3(256), 0, st,
+                       (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per, e);
 }
 
-// X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> part
+template <int EPI>
+static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
+                              int ksp, const GemmEpi &e, hipStream_t st) {
+    const int MT = Mpad / 16;
+    if (MT == 1) launch_gemm_bf16<1, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else if (MT == 2) launch_gemm_bf16<2, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else if (MT <= 4) launch_gemm_bf16<4, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else { sd_set_error("gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
+    return SD_OK;
+}
+
+// X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> split-K slabs in s->part
 static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
@@ -298,11 +309,9 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
         gemm_split(N, K, &S, &ksp);
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
-        const int MT = Mpad / 16;
-        if (MT == 1) launch_gemm_bf16<1>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
-        else if (MT == 2) launch_gemm_bf16<2>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
-        else if (MT <= 4) launch_gemm_bf16<4>(W, X, s->part, M, Mpad, N, K, S, ksp, st);
-        else { sd_set_error("run_gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
+        GemmEpi e = {};
+        const int rc = dispatch_gemm_bf16<EPI_PART>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
+        if (rc != SD_OK) return rc;
         go->S = S;
         go->stride_s = (size_t)Mpad * N;
     } else {
@@ -311,6 +320,18 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
         go->S = 1;
         go->stride_s = (size_t)M * N;
     }
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// bf16 GEMM whose workgroups keep the whole k-range (SB = 1) and finish with a fused epilogue
+template <int EPI>
+static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, int N, int K, const GemmEpi &e,
+                          hipStream_t st) {
+    ProfScope ps(s, PC_GEMM, st);
+    const int Mpad = (int)align_up(M, 16);
+    const int rc = dispatch_gemm_bf16<EPI>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);
+    if (rc != SD_OK) return rc;
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -341,6 +362,7 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     const bool llama = c.arch == SD_ARCH_LLAMA;
     const int norm_kind = llama ? NORM_RMS : NORM_LN;
     const bool pre = llama || c.opt_pre_ln;
+    const bool fused = c.dtype == SD_BF16 && c.fused_layout != 0;
     T *x = (T *)s->x, *h = (T *)s->h, *qb = (T *)s->qbuf, *at = (T *)s->attn, *ac = (T *)s->act, *eb = (T *)s->ebuf;
     const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
     const size_t layer_kv = (size_t)2 * c.n_kv_heads * s->max_seq * D;      // elements per layer
@@ -382,8 +404,18 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
         T *karena = (T *)s->kv + (size_t)l * layer_kv;
         T *varena = karena + (size_t)c.n_kv_heads * s->max_seq * D;
         // qkv projection -> rope / scale -> q buffer + in-place KV append
-        if ((rc = run_gemm(s, m->wqkv[l], h, n_new, qkv_cols(c), H, &go, st)) != SD_OK) return rc;
-        {
+        if (fused) {
+            GemmEpi e = {};
+            e.out = (bf16_t *)qb; e.bias = (const bf16_t *)m->bqkv[l];
+            e.karena = (bf16_t *)karena; e.varena = (bf16_t *)varena;
+            e.cos_t = (const bf16_t *)m->w.rope_cos; e.sin_t = (const bf16_t *)m->w.rope_sin;
+            e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.pos0 = pos0; e.max_seq = s->max_seq;
+            e.q_scale = 1.0f / sqrtf((float)D);
+            rc = llama ? run_gemm_fused<EPI_QKV_ROPE>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st)
+                       : run_gemm_fused<EPI_QKV_PLAIN>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st);
+            if (rc != SD_OK) return rc;
+        } else {
+            if ((rc = run_gemm(s, m->wqkv[l], h, n_new, qkv_cols(c), H, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_QKV, st);
             hipLaunchKernelGGL((qkv_epilogue_kernel<T>), dim3(n_new, c.n_heads + 2 * c.n_kv_heads),
                                dim3(std::max(D / 2, 64)), 0, st, s->part, go.S, go.stride_s, qkv_cols(c),
@@ -414,8 +446,14 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
             SD_LAUNCH_CHECK();
         }
         // MLP
-        if ((rc = run_gemm(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
-        {
+        if (fused) {
+            GemmEpi e = {};
+            e.out = (bf16_t *)ac; e.bias = (const bf16_t *)m->bfc1[l]; e.n_out = I;
+            rc = llama ? run_gemm_fused<EPI_ACT_SILU>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)
+                       : run_gemm_fused<EPI_ACT_RELU>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st);
+            if (rc != SD_OK) return rc;
+        } else {
+            if ((rc = run_gemm(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_ACT, st);
             hipLaunchKernelGGL((act_kernel<T>), dim3((I + 255) / 256, n_new), dim3(256), 0, st, s->part, go.S,
                                go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac);
@@ -492,10 +530,8 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, i
     const int Mpad = (int)align_up(M, 16);
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
-    const int MT = Mpad / 16;
-    if (MT == 1) launch_gemm_bf16<1>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
-    else if (MT == 2) launch_gemm_bf16<2>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
-    else launch_gemm_bf16<4>(w_packed, x, part, M, Mpad, N, K, S, ksp, st);
+    GemmEpi e = {};
+    if (dispatch_gemm_bf16<EPI_PART>(w_packed, x, part, M, Mpad, N, K, S, ksp, e, st) != SD_OK) return SD_ERR_INVALID;
     SD_LAUNCH_CHECK();
     if (out) {
         hipLaunchKernelGGL(reduce_f32_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, S,

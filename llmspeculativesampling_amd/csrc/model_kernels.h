@@ -18,10 +18,28 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 // The MFMA runs with A = W tile (rows n), B = X^T (cols m): lane holds D[n = 4*(lane>>4)+j][m = lane&15],
 // so each lane stores 4 consecutive n as one float4.
 // ------------------------------------------------------------------------------------------
-template <int MT, int UNROLL>
+enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4 };
+
+// Arguments of the fused epilogues (SB == 1: the workgroup holds the whole dot product after its LDS fold).
+struct GemmEpi {
+    bf16_t *out;              // ACT: act[M][n_out]            QKV: q buffer [M][Hq*D]
+    const bf16_t *bias;       // OPT biases (NULL for llama)
+    int n_out;                // ACT: row stride of act (= inter)
+    bf16_t *karena, *varena;  // QKV: this layer's K / V arena [Hkv][max_seq][D]
+    const bf16_t *cos_t, *sin_t;
+    int Hq, Hkv, D, pos0, max_seq;
+    float q_scale;
+};
+
+__device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, float d) {
+    const bf16_t v[4] = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
+}
+
+template <int MT, int UNROLL, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
                                                        float *__restrict__ part, int M, int Mpad, int N, int K,
-                                                       int SB, int ks_per_blk) {
+                                                       int SB, int ks_per_blk, GemmEpi e) {
     // One workgroup = one 16-column n-tile x one k-slab; its 4 waves take a quarter of the slab each and fold
     // their accumulators through LDS, so the number of partial slabs in HBM is SB, not 4*SB.
     __shared__ f32x4 red[4][MT][64];
@@ -80,12 +98,78 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
     for (int t = 0; t < MT; ++t) red[wv][t][lane] = acc[t];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
-        const int t = idx >> 6, l = idx & 63;
-        const int m = t * 16 + (l & 15);
-        if (m < M) {
-            const f32x4 r = (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]);
-            *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = r;
+    auto folded = [&](int t, int l) -> f32x4 { return (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]); };
+    if constexpr (EPI == EPI_PART) {
+        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
+            const int t = idx >> 6, l = idx & 63;
+            const int m = t * 16 + (l & 15);
+            if (m < M)
+                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(t, l);
+        }
+    } else if constexpr (EPI == EPI_ACT_SILU) {
+        // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
+        for (int idx = threadIdx.x; idx < MT * 32; idx += 256) {
+            const int t = idx >> 5, l = idx & 31;
+            const int m = t * 16 + (l & 15);
+            if (m < M) {
+                const f32x4 g = folded(t, l), u = folded(t, l + 32);
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gj = rnd<bf16_t>(g[j]), uj = rnd<bf16_t>(u[j]);
+                    a[j] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                }
+                store4(e.out + (size_t)m * e.n_out + nt * 8 + (l >> 4) * 4, a[0], a[1], a[2], a[3]);
+            }
+        }
+    } else if constexpr (EPI == EPI_ACT_RELU) {
+        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
+            const int t = idx >> 6, l = idx & 63;
+            const int m = t * 16 + (l & 15), col = nt * 16 + (l >> 4) * 4;
+            if (m < M) {
+                const f32x4 r = folded(t, l);
+                float a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float f = rnd<bf16_t>(r[j] + (e.bias ? to_f(e.bias[col + j]) : 0.f));
+                    a[j] = f > 0.f ? f : 0.f;
+                }
+                store4(e.out + (size_t)m * e.n_out + col, a[0], a[1], a[2], a[3]);
+            }
+        }
+    } else {
+        // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
+        // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
+        const int hd = e.D >> 1;
+        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
+            const int t = idx >> 6, l = idx & 63;
+            const int m = t * 16 + (l & 15), col = nt * 16 + (l >> 4) * 4;
+            if (m >= M) continue;
+            const f32x4 r = folded(t, l);
+            const int head = col / e.D, within = col - head * e.D;
+            const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
+            bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
+                               : (is_k ? e.karena + ((size_t)(head - e.Hq) * e.max_seq + e.pos0 + m) * e.D
+                                       : e.varena + ((size_t)(head - e.Hq - e.Hkv) * e.max_seq + e.pos0 + m) * e.D);
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = rnd<bf16_t>(r[j] + (e.bias ? to_f(e.bias[col + j]) : 0.f));
+            if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int d = (within >> 1) + pr;
+                    const float c = to_f(e.cos_t[(size_t)(e.pos0 + m) * hd + d]), sn = to_f(e.sin_t[(size_t)(e.pos0 + m) * hd + d]);
+                    const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
+                    dst[d] = (bf16_t)(rnd<bf16_t>(x0 * c) + rnd<bf16_t>(-x1 * sn));
+                    dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * c) + rnd<bf16_t>(x0 * sn));
+                }
+            } else {
+                if (EPI == EPI_QKV_PLAIN && is_q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = rnd<bf16_t>(x[j] * e.q_scale);
+                }
+                store4(dst + within, x[0], x[1], x[2], x[3]);
+            }
         }
     }
 }

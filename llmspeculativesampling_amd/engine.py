@@ -48,6 +48,7 @@ class SpecDecModel:
         self._keep: List[torch.Tensor] = []          # owns every device tensor the handle points into
         self._arrays = []
         self.weight_bytes = 0                        # bytes the forward streams (embedding tables excluded)
+        self.fused = dtype == torch.bfloat16 and cfg.intermediate_size % 8 == 0 and cfg.head_dim % 4 == 0
         self._build(get_tensor)
 
     # -- weight staging ---------------------------------------------------------------------
@@ -84,12 +85,22 @@ class SpecDecModel:
                 w.embed = _ptr(self._dev(get("model.embed_tokens.weight")))
                 for i in range(L):
                     p = f"model.layers.{i}."
-                    q, k, v = (get(p + f"self_attn.{n}_proj.weight") for n in "qkv")
-                    wqkv.append(self._gemm_weight(torch.cat([q.to(self.device), k.to(self.device), v.to(self.device)], 0)))
+                    q, k, v = (get(p + f"self_attn.{n}_proj.weight").to(self.device) for n in "qkv")
+                    if self.fused:
+                        # pair-interleave the rows of every q / k head: d0, d0+D/2, d1, d1+D/2, ... so that one
+                        # accumulator quad of the GEMM holds two complete RoPE pairs (specdec.h, fused_layout)
+                        D, K = cfg.head_dim, q.shape[1]
+                        q = q.view(-1, 2, D // 2, K).transpose(1, 2).reshape(-1, K)
+                        k = k.view(-1, 2, D // 2, K).transpose(1, 2).reshape(-1, K)
+                    wqkv.append(self._gemm_weight(torch.cat([q, k, v], 0)))
                     del q, k, v
                     wo.append(self._gemm_weight(get(p + "self_attn.o_proj.weight")))
-                    g, u = get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")
-                    wgu.append(self._gemm_weight(torch.cat([g.to(self.device), u.to(self.device)], 0)))
+                    g, u = get(p + "mlp.gate_proj.weight").to(self.device), get(p + "mlp.up_proj.weight").to(self.device)
+                    if self.fused:
+                        K = g.shape[1]                        # 8 gate rows, the same 8 up rows, ...
+                        wgu.append(self._gemm_weight(torch.stack([g.view(-1, 8, K), u.view(-1, 8, K)], 1).reshape(-1, K)))
+                    else:
+                        wgu.append(self._gemm_weight(torch.cat([g, u], 0)))
                     del g, u
                     wdn.append(self._gemm_weight(get(p + "mlp.down_proj.weight")))
                     n1w.append(self._dev(get(p + "input_layernorm.weight")))
@@ -146,7 +157,7 @@ class SpecDecModel:
             n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
             max_pos=self.max_pos, opt_pre_ln=int(cfg.do_layer_norm_before), opt_proj_dim=cfg.word_embed_proj_dim or cfg.hidden_size,
             norm_eps=cfg.rms_norm_eps if cfg.arch == "llama" else cfg.layer_norm_eps,
-            logits_bf16_round=int(self.dtype == torch.bfloat16))
+            logits_bf16_round=int(self.dtype == torch.bfloat16), fused_layout=int(self.fused))
         h = C.c_void_p()
         check(lib.sd_model_create(C.byref(c), C.byref(w), C.byref(h)), "sd_model_create")
         self.handle = h
