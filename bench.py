@@ -237,9 +237,20 @@ def main():
     S_mean = float(np.mean(ver_S)) if ver_S else float(args.prompt_len + args.max_len / 2)
     b_ver = algorithmic_verify_bytes(tcfg, args.gamma, S_mean)
     achieved = b_ver / (t_ver * 1e-3) / 1e9 if ver_ms else float("nan")
+    # HBM traffic per verify step from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and
+    # WRITE_SIZE do not fit one pass and cannot be combined with the timed run), so the committed summary of the
+    # latest such run is read here (tools/pmc_traffic.py; gfx950 half-count correction applied, calibrated on a
+    # GEMM whose bytes are known).
+    traffic = None
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        if cands and args.target == "llama-2-13b" and args.gamma == 4:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["traffic_bytes_per_verify"]
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel": "verify step (target forward over gamma+1 rows: gemm_bf16_stream chain + attention + epilogues + norm_probs)",
         "algorithmic_bytes_per_launch": b_ver, "avg_launch_ms": t_ver, "launches_timed": len(ver_ms),
         "mean_context": S_mean,
