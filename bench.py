@@ -156,12 +156,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local)
+    # rehearsal on a one-GPU box: SPECDEC_DIST_BACKEND=gloo puts every rank on cuda:0 and the collectives on the host
+    backend = os.environ.get("SPECDEC_DIST_BACKEND", "nccl")
+    torch.cuda.set_device(local if backend == "nccl" else 0)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from llmspeculativesampling_amd.config import load_config
     from llmspeculativesampling_amd.engine import SpecDecModel
@@ -211,11 +214,11 @@ def main():
         # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
         from llmspeculativesampling_amd.dist import gather_streams
         width = args.prompt_len + args.max_len + args.gamma + 1
-        all_streams = gather_streams(outs, args.steps * world, width, device="cuda")
+        all_streams = gather_streams(outs, args.steps * world, width, device=comm_dev)
         assert len(all_streams) == args.steps * world
     barrier()
     elapsed = time.time() - t0
-    stats = torch.tensor([elapsed, float(new_tokens), float(acc_sum), float(n_iters)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(new_tokens), float(acc_sum), float(n_iters)], dtype=torch.float64, device=comm_dev)
     if dist is not None:
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -398,3 +398,80 @@ def test_norm_sample_fused_matches_two_step(hip):
             assert int(tok) == int(want) and not bool(err.any())
             ref = oracle.sample(oracle.norm_logits(x.cpu(), T, k, p), oracle.RecordedNoise([("exp", noise.cpu()[None])]))
             assert int(tok) == int(ref)
+
+
+# --------------------------------------------------------------------------- production head sizes / long prompts
+MID_CFGS = {
+    "llama_d128": dict(arch="llama", vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5),
+    "llama_d64_gqa": dict(arch="llama", vocab_size=1024, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6),
+    "opt_d32_post": dict(arch="opt", vocab_size=1024, hidden_size=128, ffn_dim=256, num_hidden_layers=2,
+                         num_attention_heads=4, max_position_embeddings=512, do_layer_norm_before=False,
+                         word_embed_proj_dim=64),
+    "opt_d64_pre": dict(arch="opt", vocab_size=1024, hidden_size=128, ffn_dim=512, num_hidden_layers=2,
+                        num_attention_heads=2, max_position_embeddings=512, do_layer_norm_before=True,
+                        word_embed_proj_dim=128),
+}
+
+
+@pytest.mark.parametrize("name", list(MID_CFGS))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_forward_production_head_dims_vs_oracle(hip, name, dtype):
+    """Head dims 32 / 64 / 128 (the MFMA QK^T path), GQA, a 150-token prompt fed as 64-row chunks, then
+    incremental steps of 1, 2, 5 and 9 rows (more rows than one attention row-group), against the oracle forward
+    in the same dtype.  fp32: 1e-3 (north_star); bf16: the two bf16 pipelines round at the same points, so they
+    agree to a few bf16 ulps of the logit scale."""
+    from llmspeculativesampling_amd.config import ModelConfig
+    cfg = ModelConfig(**MID_CFGS[name])
+    sd = make_state_dict(cfg, 77, dtype=dtype)
+    om = oracle.RefCausalLM(cfg, sd)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    ses = m.new_session(256)
+    ids = torch.from_numpy(np.random.default_rng(9).integers(3, cfg.vocab_size, size=(1, 167)))
+    past, pos = None, 0
+    for q in (150, 1, 2, 5, 9):
+        chunk = ids[:, pos:pos + q]
+        o = om(chunk, past_key_values=past)
+        past = o.past_key_values
+        nl = min(q, 9)
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), nl).cpu()
+        want = o.logits.float()[0, -nl:]
+        scale = float(want.abs().max())
+        tol = 1e-3 if dtype == torch.float32 else 0.04 * scale
+        assert float((got - want).abs().max()) <= tol, (name, q, float((got - want).abs().max()), scale)
+        pos += q
+    k, v = ses.past_key_values()[1]
+    ok, ov = past[1]
+    ktol = 1e-4 if dtype == torch.float32 else 0.05
+    assert float((k.float().cpu() - ok.float()).abs().max()) <= ktol * max(1.0, float(ok.float().abs().max()))
+    assert float((v.float().cpu() - ov.float()).abs().max()) <= ktol * max(1.0, float(ov.float().abs().max()))
+
+
+def test_speculative_bf16_statistics_vs_oracle(hip):
+    """bf16 end to end (fused epilogues, MFMA attention): same recorded noise into the oracle's bf16 CPU run and the
+    HIP run.  bf16 rounding-order differences may flip an occasional token, so the bar is statistical: accept-length
+    histograms within a few counts and most iterations token-identical until the first divergence."""
+    from llmspeculativesampling_amd.config import ModelConfig
+    from llmspeculativesampling_amd.synth import perturb_state_dict
+    cfg = ModelConfig(**MID_CFGS["llama_d64_gqa"])
+    dsd = make_state_dict(cfg, 5, dtype=torch.bfloat16)
+    tsd = {k2: v2.to(torch.bfloat16) for k2, v2 in perturb_state_dict({k3: v3.float() for k3, v3 in dsd.items()}, 6, 0.08).items()}
+    prompt = torch.from_numpy(np.random.default_rng(3).integers(3, cfg.vocab_size, size=(1, 24)))
+    rec = oracle.RecordingNoise()
+    torch.manual_seed(11)
+    want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(cfg, dsd), oracle.RefCausalLM(cfg, tsd), 2, None,
+                                           40, gamma=4, top_k=20, top_p=0.9, details=True, noise=rec)
+    dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.bfloat16)
+    tm = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.bfloat16)
+    torch.manual_seed(11)
+    got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, 2, None, 40, gamma=4, top_k=20, top_p=0.9, details=True)
+    w, g = want[0].tolist(), got[0].cpu().tolist()
+    common = 0
+    for a, b in zip(w, g):
+        if a != b:
+            break
+        common += 1
+    assert common >= 24 + 8, (common, w, g)                 # identical well past the prompt
+    assert abs(float(np.mean(gd["acc_len"])) - float(np.mean(wd["acc_len"]))) <= 1.0
+    assert abs(float(gd["acc_rate"]) - float(wd["acc_rate"])) <= 0.15
