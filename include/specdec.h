@@ -81,7 +81,7 @@ typedef struct {
     int32_t n;             /* last kept position, L+l-1                    (:1964, :1983)                      */
     int32_t next_token;    /* t: residual resample or bonus sample         (:2005-2023)                        */
     int32_t flags;         /* bit0 residual was all-zero -> fallback sample(max_fn(p_n)) (:2009-2010);
-                              bit1 'prob error'; bit2 all gamma accepted                                       */
+                              bit1 'prob error'; bit2 all gamma accepted; bit3 an error word of the iteration was set */
     float p_at[16];        /* target prob of each drafted token (for the acc_rate statistic, :1966-1971)      */
     float q_at[16];        /* draft prob of each drafted token                                                */
 } sd_accept_result;
@@ -185,6 +185,28 @@ int sd_session_destroy(sd_session *s);
  * smaller pos0 next time (kvcache_model.py:359-436).  n_new <= max_rows, pos0+n_new <= max_seq. */
 int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
                        float *logits_out, long ld_logits, void *stream);
+
+/* One whole speculative iteration enqueued natively (device-RNG mode), reference speculative_sampling.py:1934-2031:
+ * gamma x (draft forward over the uncached rows + sd_norm_sample straight into seq[]), one target forward over its
+ * uncached rows + sd_norm_probs of the last gamma+1, sd_accept_scan, residual / bonus sample, then async copies of
+ * the result block and of seq[L .. L+gamma+2) into pinned host memory.  Nothing synchronises: the caller waits on
+ * the stream once per iteration.  seq: device int32 sequence buffer; q_hist / p_hist: probability arenas indexed by
+ * position (row stride ld); *_logits: scratch rows for the heads; err_words: 3*gamma+1 device ints (folded into
+ * res.flags bit3 = 'norm logits error' / sample error).  Philox draws: draft step i uses (seed_draft,
+ * draw_draft0+i); the accept uniforms (seed_accept, draw_scan0+i) unless r_const (gamma device floats: the
+ * random_seed quirk) is given; the resample (seed_accept, draw_resample). */
+typedef struct sd_spec sd_spec;
+int sd_spec_create(sd_session *draft, sd_session *target, int gamma, float temperature, int top_k, float top_p,
+                   int32_t *seq, float *q_hist, float *p_hist, long ld, float *draft_logits, long ld_draft_logits,
+                   float *target_logits, long ld_target_logits, int *err_words, sd_accept_result *res_dev,
+                   sd_spec **out);
+int sd_spec_destroy(sd_spec *sp);
+int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_t seed_draft, uint64_t draw_draft0,
+                      uint64_t seed_accept, uint64_t draw_scan0, uint64_t draw_resample, const float *r_const,
+                      sd_accept_result *res_host, int32_t *tok_host, void *stream);
+/* HIP-event timing of the draft phase and the target (verify) phase of the last iteration, on the launch stream. */
+int sd_spec_timing(sd_spec *sp, int on);
+int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms);
 
 /* Per-op-class timing for the roofline report: when enabled, every launch inside
  * sd_session_forward is bracketed with HIP events on the launch stream; sd_profile_read

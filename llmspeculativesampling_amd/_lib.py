@@ -64,6 +64,11 @@ SYMBOLS = [
     ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),
     ("sd_session_destroy", _I, [_VP]),
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
+    ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, C.POINTER(_VP)]),
+    ("sd_spec_destroy", _I, [_VP]),
+    ("sd_spec_iteration", _I, [_VP, _I, _I, _I, _U64, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP]),
+    ("sd_spec_timing", _I, [_VP, _I]),
+    ("sd_spec_last_times", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("sd_profile_enable", _I, [_VP, _I]),
     ("sd_profile_read", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 ]

@@ -104,8 +104,10 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // ---- split-K policy.  A workgroup (4 waves) owns one n-tile x one k-slab and folds its waves in LDS, so
 // SB slabs reach HBM.  SB is chosen so that about `target` workgroups exist (>= 4 per CU), with at least
 // 8 k-steps (8 KiB of weights) per workgroup.
-static void gemm_split(int N, int K, int *S_out, int *ks_per_out) {
-    const int NTL = N / 16, KS = K / 32;
+static int gemm_ntw(int N, int M) { return (M > 16 && (N / 16) % 4 == 0) ? 4 : 1; }
+
+static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
+    const int NTL = N / 16 / gemm_ntw(N, M), KS = K / 32;
     int max_s = KS / 8;
     if (max_s < 1) max_s = 1;
     int S = 1;
@@ -134,9 +136,13 @@ static void gemm_split(int N, int K, int *S_out, int *ks_per_out) {
 
 static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
     if (c.dtype != SD_BF16) return (size_t)rows * N;
-    int S, ksp;
-    gemm_split(N, K, &S, &ksp);
-    return (size_t)S * align_up(rows, 16) * N;
+    size_t best = 0;
+    for (int m : {1, rows}) {
+        int S, ksp;
+        gemm_split(N, K, m, &S, &ksp);
+        best = std::max(best, (size_t)S * align_up(m, 16) * N);
+    }
+    return best;
 }
 
 static int qkv_cols(const sd_model_config &c) { return (c.n_heads + 2 * c.n_kv_heads) * c.head_dim; }
@@ -281,11 +287,11 @@ struct GemmOut {
     size_t stride_s;   // floats between k-slices
 };
 
-template <int MT, int EPI>
+template <int MT, int EPI, int NTW>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
                              int ks_per, const GemmEpi &e, hipStream_t st) {
-    const int blocks = (N / 16) * S;
-    hipLaunchKernelGGL((gemm_bf16_stream<MT, 8 / (MT > 2 ? 2 : 1), EPI>), dim3(blocks), dim3(256), 0, st,
+    const int blocks = (N / 16 / NTW) * S;
+    hipLaunchKernelGGL((gemm_bf16_stream<MT, (MT > 2 ? 2 : (NTW > 1 ? 4 : 8)), EPI, NTW>), dim3(blocks), dim3(256), 0, st,
                        (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per, e);
 }
 
@@ -293,9 +299,12 @@ template <int EPI>
 static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
                               int ksp, const GemmEpi &e, hipStream_t st) {
     const int MT = Mpad / 16;
-    if (MT == 1) launch_gemm_bf16<1, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-    else if (MT == 2) launch_gemm_bf16<2, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-    else if (MT <= 4) launch_gemm_bf16<4, EPI>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    const bool wide = gemm_ntw(N, M) == 4;       // prefill rows: 4 n-tiles per workgroup reuse every activation fragment
+    if (MT == 1) launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else if (MT == 2) { if (wide) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<2, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
+    else if (MT <= 4) { if (wide) launch_gemm_bf16<4, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<4, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else { sd_set_error("gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
     return SD_OK;
 }
@@ -306,7 +315,7 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
     ProfScope ps(s, PC_GEMM, st);
     if (c.dtype == SD_BF16) {
         int S, ksp;
-        gemm_split(N, K, &S, &ksp);
+        gemm_split(N, K, M, &S, &ksp);
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
         GemmEpi e = {};
@@ -526,7 +535,7 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, i
     SD_REQUIRE(w_packed && x && part, "sd_gemm_bf16: null argument");
     SD_REQUIRE(M >= 1 && M <= 64 && N % 16 == 0 && K % 32 == 0, "sd_gemm_bf16: need 1<=M<=64, N%%16==0, K%%32==0");
     int S, ksp;
-    gemm_split(N, K, &S, &ksp);
+    gemm_split(N, K, M, &S, &ksp);
     const int Mpad = (int)align_up(M, 16);
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
@@ -539,5 +548,139 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, i
         SD_LAUNCH_CHECK();
     }
     if (splits_out) *splits_out = S;
+    return SD_OK;
+}
+
+// ---- one whole speculative iteration, enqueued natively ---------------------------------------
+// reference sampling/speculative_sampling.py:1934-2031 for the device-RNG mode: gamma x (draft forward +
+// norm_sample), one target forward over the uncached rows + norm_probs, accept scan, residual / bonus sample,
+// then the 144-byte result block and the gamma+2 candidate tokens are copied to pinned host memory.  Nothing
+// here synchronises; the caller waits on the stream once per iteration.
+int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
+                            uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res, const int *err_flags,
+                            int n_err, hipStream_t st);
+
+struct sd_spec {
+    sd_session *draft, *target;
+    int gamma, top_k, V;
+    float temperature, top_p;
+    int32_t *seq;
+    float *q_hist, *p_hist;
+    long ld;
+    float *draft_logits, *target_logits;
+    long ld_dl, ld_tl;
+    int *err;                    // device ints: [0..gamma) norm err of draft rows, [gamma..2gamma) sample err, [2gamma..3gamma+1) target rows
+    sd_accept_result *res_dev;
+    hipEvent_t ev[4];
+    int timing;
+};
+
+extern "C" int sd_spec_create(sd_session *draft, sd_session *target, int gamma, float temperature, int top_k,
+                              float top_p, int32_t *seq, float *q_hist, float *p_hist, long ld, float *draft_logits,
+                              long ld_draft_logits, float *target_logits, long ld_target_logits, int *err_words,
+                              sd_accept_result *res_dev, sd_spec **out) {
+    SD_REQUIRE(draft && target && seq && q_hist && p_hist && draft_logits && target_logits && err_words && res_dev && out,
+               "sd_spec_create: null argument");
+    SD_REQUIRE(gamma >= 1 && gamma <= 16, "sd_spec_create: gamma must be in 1..16");
+    SD_REQUIRE(draft->m->cfg.vocab == target->m->cfg.vocab, "sd_spec_create: draft and target vocabularies differ");
+    SD_REQUIRE(temperature != 0.0f, "sd_spec_create: temperature must be non-zero");
+    sd_spec *sp = new sd_spec();
+    sp->draft = draft; sp->target = target; sp->gamma = gamma; sp->temperature = temperature; sp->top_k = top_k;
+    sp->top_p = top_p; sp->V = draft->m->cfg.vocab; sp->seq = seq; sp->q_hist = q_hist; sp->p_hist = p_hist; sp->ld = ld;
+    sp->draft_logits = draft_logits; sp->ld_dl = ld_draft_logits; sp->target_logits = target_logits; sp->ld_tl = ld_target_logits;
+    sp->err = err_words; sp->res_dev = res_dev; sp->timing = 0;
+    for (int i = 0; i < 4; ++i) SD_HIP_CHECK(hipEventCreate(&sp->ev[i]));
+    *out = sp;
+    return SD_OK;
+}
+
+extern "C" int sd_spec_destroy(sd_spec *sp) {
+    if (!sp) return SD_OK;
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(sp->ev[i]);
+    delete sp;
+    return SD_OK;
+}
+
+extern "C" int sd_spec_timing(sd_spec *sp, int on) {
+    SD_REQUIRE(sp, "sd_spec_timing: null handle");
+    sp->timing = on;
+    return SD_OK;
+}
+
+// milliseconds of the last iteration's draft phase and target (verify) phase; call after the stream is synchronised
+extern "C" int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms) {
+    SD_REQUIRE(sp && draft_ms && target_ms && sp->timing, "sd_spec_last_times: timing is off");
+    SD_HIP_CHECK(hipEventElapsedTime(draft_ms, sp->ev[0], sp->ev[1]));
+    SD_HIP_CHECK(hipEventElapsedTime(target_ms, sp->ev[2], sp->ev[3]));
+    return SD_OK;
+}
+
+extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
+                              int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
+                              uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *stream);
+extern "C" int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
+                             float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
+                             void *stream);
+extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld, const int32_t *seq, int L, int gamma,
+                              const float *r, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *out,
+                              void *stream);
+
+// feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows
+static int feed_rows(sd_session *ses, const int32_t *seq, int from, int upto, int n_logits, float *logits, long ld,
+                     void *stream) {
+    const int first_logit = upto - n_logits;
+    int done = from;
+    while (done < upto) {
+        const int m = std::min(ses->max_rows, upto - done);
+        const int lo = std::max(first_logit, done);
+        const int nl = std::max(0, done + m - lo);
+        const int rc = sd_session_forward(ses, seq + done, m, done, nl, nl ? logits + (size_t)(lo - first_logit) * ld : nullptr,
+                                          ld, stream);
+        if (rc != SD_OK) return rc;
+        done += m;
+    }
+    return SD_OK;
+}
+
+extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_t seed_draft,
+                                 uint64_t draw_draft0, uint64_t seed_accept, uint64_t draw_scan0,
+                                 uint64_t draw_resample, const float *r_const, sd_accept_result *res_host,
+                                 int32_t *tok_host, void *stream) {
+    SD_REQUIRE(sp && res_host && tok_host, "sd_spec_iteration: null argument");
+    SD_REQUIRE(L >= 1 && draft_len >= 0 && draft_len < L && target_len >= 0 && target_len < L + sp->gamma,
+               "sd_spec_iteration: L=%d draft_len=%d target_len=%d", L, draft_len, target_len);
+    hipStream_t st = (hipStream_t)stream;
+    const int g = sp->gamma, V = sp->V;
+    int rc;
+    if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[0], st));
+    // ---- draft: gamma steps; the sampled token goes straight into seq[] where the next step's embed reads it
+    for (int i = 0; i < g; ++i) {
+        const int upto = L + i;
+        if ((rc = feed_rows(sp->draft, sp->seq, draft_len, upto, 1, sp->draft_logits, sp->ld_dl, stream)) != SD_OK) return rc;
+        draft_len = upto;
+        if ((rc = sd_norm_sample(sp->draft_logits, V, sp->temperature, sp->top_k, sp->top_p, 0,
+                                 sp->q_hist + (size_t)(upto - 1) * sp->ld, sp->err + i, nullptr, seed_draft,
+                                 draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, stream)) != SD_OK)
+            return rc;
+    }
+    if (sp->timing) { SD_HIP_CHECK(hipEventRecord(sp->ev[1], st)); SD_HIP_CHECK(hipEventRecord(sp->ev[2], st)); }
+    // ---- target: every uncached row in one pass (the whole prompt on the first call), logits for the last gamma+1
+    {
+        const int upto = L + g;
+        const int rows = std::min(upto - target_len, g + 1);
+        if ((rc = feed_rows(sp->target, sp->seq, target_len, upto, rows, sp->target_logits, sp->ld_tl, stream)) != SD_OK) return rc;
+        if ((rc = sd_norm_probs(sp->target_logits, rows, V, sp->ld_tl, sp->temperature, sp->top_k, sp->top_p, 0,
+                                sp->p_hist + (size_t)(upto - rows) * sp->ld, sp->ld, sp->err + 2 * g, stream)) != SD_OK)
+            return rc;
+    }
+    if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[3], st));
+    // ---- accept scan + residual / bonus sample
+    if ((rc = sd_accept_scan(sp->p_hist, sp->q_hist, sp->ld, sp->seq, L, g, r_const, seed_accept, draw_scan0, sp->res_dev, stream)) != SD_OK)
+        return rc;
+    if ((rc = sd_resample_with_errors(sp->p_hist, sp->q_hist, sp->ld, V, sp->seq, g, seed_accept, draw_resample, sp->res_dev,
+                                      sp->err, 3 * g + 1, st)) != SD_OK)
+        return rc;
+    SD_HIP_CHECK(hipMemcpyAsync(res_host, sp->res_dev, sizeof(sd_accept_result), hipMemcpyDeviceToHost, st));
+    SD_HIP_CHECK(hipMemcpyAsync(tok_host, sp->seq + L, sizeof(int32_t) * (size_t)(g + 2), hipMemcpyDeviceToHost, st));
     return SD_OK;
 }

@@ -36,20 +36,23 @@ __device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, f
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
-template <int MT, int UNROLL, int EPI>
+template <int MT, int UNROLL, int EPI, int NTW>
 __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
                                                        float *__restrict__ part, int M, int Mpad, int N, int K,
                                                        int SB, int ks_per_blk, GemmEpi e) {
-    // One workgroup = one 16-column n-tile x one k-slab; its 4 waves take a quarter of the slab each and fold
-    // their accumulators through LDS, so the number of partial slabs in HBM is SB, not 4*SB.
-    __shared__ f32x4 red[4][MT][64];
+    // One workgroup = NTW consecutive 16-column n-tiles x one k-slab; its 4 waves take a quarter of the slab each
+    // (every activation fragment a wave loads is reused for NTW weight tiles) and fold their accumulators through
+    // LDS, so the number of partial slabs in HBM is SB, not 4*SB.  NTW = 1 for decode (M <= 16), 4 for prefill rows.
+    __shared__ f32x4 red[4][NTW][MT][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int NTL = N >> 4, KS = K >> 5;
-    const int sb = blockIdx.x / NTL, nt = blockIdx.x - sb * NTL;
+    const int NTG = (N >> 4) / NTW, KS = K >> 5;
+    const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
     const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
     const int per = (kb1 - kb0 + 3) >> 2;
     const int ks0 = min(kb1, kb0 + wv * per), ks1 = min(kb1, ks0 + per);
-    const u32x4 *wp = Wp + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4 *wp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wp[j] = Wp + ((size_t)(ntg * NTW + j) * KS + ks0) * 64 + lane;
     const int mrow = lane & 15, kq = (lane >> 4) * 8;
     const bf16_t *xp[MT];
     bool mv[MT];
@@ -59,16 +62,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         mv[t] = m < M;
         xp[t] = X + (size_t)(mv[t] ? m : 0) * K + (size_t)ks0 * 32 + kq;
     }
-    f32x4 acc[MT];
+    f32x4 acc[NTW][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int ks = ks0;
     for (; ks + UNROLL <= ks1; ks += UNROLL) {
-        u32x4 w[UNROLL];
+        u32x4 w[UNROLL][NTW];
         u32x4 x[UNROLL][MT];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)u * 64);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -77,62 +84,72 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u]),
-                                                                __builtin_bit_cast(bf16x8, x[u][t]), acc[t], 0, 0, 0);
-        wp += (size_t)UNROLL * 64;
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u][j]),
+                                                                       __builtin_bit_cast(bf16x8, x[u][t]), acc[j][t], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wp[j] += (size_t)UNROLL * 64;
 #pragma unroll
         for (int t = 0; t < MT; ++t) xp[t] += UNROLL * 32;
     }
     for (; ks < ks1; ++ks) {
-        const u32x4 w = __builtin_nontemporal_load(wp);
+        u32x4 w[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) { w[j] = __builtin_nontemporal_load(wp[j]); wp[j] += 64; }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const u32x4 x = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t]) : u32x4{0u, 0u, 0u, 0u};
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
-                                                            __builtin_bit_cast(bf16x8, x), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]),
+                                                                   __builtin_bit_cast(bf16x8, x), acc[j][t], 0, 0, 0);
             xp[t] += 32;
         }
-        wp += 64;
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) red[wv][t][lane] = acc[t];
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[wv][j][t][lane] = acc[j][t];
     __syncthreads();
-    auto folded = [&](int t, int l) -> f32x4 { return (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]); };
+    auto folded = [&](int j, int t, int l) -> f32x4 {
+        return (red[0][j][t][l] + red[1][j][t][l]) + (red[2][j][t][l] + red[3][j][t][l]);
+    };
     if constexpr (EPI == EPI_PART) {
-        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
-            const int t = idx >> 6, l = idx & 63;
-            const int m = t * 16 + (l & 15);
+        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
+            const int m = t * 16 + (l & 15), nt = ntg * NTW + j;
             if (m < M)
-                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(t, l);
+                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(j, t, l);
         }
     } else if constexpr (EPI == EPI_ACT_SILU) {
         // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
-        for (int idx = threadIdx.x; idx < MT * 32; idx += 256) {
-            const int t = idx >> 5, l = idx & 31;
-            const int m = t * 16 + (l & 15);
+        for (int idx = threadIdx.x; idx < NTW * MT * 32; idx += 256) {
+            const int j = idx / (MT * 32), r2 = idx - j * (MT * 32), t = r2 >> 5, l = r2 & 31;
+            const int m = t * 16 + (l & 15), nt = ntg * NTW + j;
             if (m < M) {
-                const f32x4 g = folded(t, l), u = folded(t, l + 32);
+                const f32x4 g = folded(j, t, l), u = folded(j, t, l + 32);
                 float a[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gj = rnd<bf16_t>(g[j]), uj = rnd<bf16_t>(u[j]);
-                    a[j] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                for (int q = 0; q < 4; ++q) {
+                    const float gj = rnd<bf16_t>(g[q]), uj = rnd<bf16_t>(u[q]);
+                    a[q] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
                 }
                 store4(e.out + (size_t)m * e.n_out + nt * 8 + (l >> 4) * 4, a[0], a[1], a[2], a[3]);
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
-        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
-            const int t = idx >> 6, l = idx & 63;
-            const int m = t * 16 + (l & 15), col = nt * 16 + (l >> 4) * 4;
+        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
+            const int m = t * 16 + (l & 15), col = (ntg * NTW + j) * 16 + (l >> 4) * 4;
             if (m < M) {
-                const f32x4 r = folded(t, l);
+                const f32x4 r = folded(j, t, l);
                 float a[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float f = rnd<bf16_t>(r[j] + (e.bias ? to_f(e.bias[col + j]) : 0.f));
-                    a[j] = f > 0.f ? f : 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const float f = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
+                    a[q] = f > 0.f ? f : 0.f;
                 }
                 store4(e.out + (size_t)m * e.n_out + col, a[0], a[1], a[2], a[3]);
             }
@@ -141,11 +158,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
         // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
         const int hd = e.D >> 1;
-        for (int idx = threadIdx.x; idx < MT * 64; idx += 256) {
-            const int t = idx >> 6, l = idx & 63;
-            const int m = t * 16 + (l & 15), col = nt * 16 + (l >> 4) * 4;
+        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
+            const int m = t * 16 + (l & 15), col = (ntg * NTW + j) * 16 + (l >> 4) * 4;
             if (m >= M) continue;
-            const f32x4 r = folded(t, l);
+            const f32x4 r = folded(j, t, l);
             const int head = col / e.D, within = col - head * e.D;
             const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
             bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
                                        : e.varena + ((size_t)(head - e.Hq - e.Hkv) * e.max_seq + e.pos0 + m) * e.D);
             float x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = rnd<bf16_t>(r[j] + (e.bias ? to_f(e.bias[col + j]) : 0.f));
+            for (int q = 0; q < 4; ++q) x[q] = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
             if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             } else {
                 if (EPI == EPI_QKV_PLAIN && is_q) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = rnd<bf16_t>(x[j] * e.q_scale);
+                    for (int q = 0; q < 4; ++q) x[q] = rnd<bf16_t>(x[q] * e.q_scale);
                 }
                 store4(dst + within, x[0], x[1], x[2], x[3]);
             }

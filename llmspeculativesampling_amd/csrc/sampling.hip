@@ -560,7 +560,8 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
                                                      int32_t *__restrict__ seq, int gamma,
                                                      const float *__restrict__ noise, uint64_t seed, uint64_t draw,
                                                      sd_accept_result *__restrict__ res,
-                                                     int32_t *__restrict__ seq_len) {
+                                                     int32_t *__restrict__ seq_len,
+                                                     const int *__restrict__ err_flags, int n_err) {
     __shared__ SampleShared S;
     __shared__ float red[16];
     const int n = res->n;
@@ -591,6 +592,8 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
     }
     if (threadIdx.x == 0) {
         if (status != 0) flags |= 2;
+        for (int i = 0; i < n_err; ++i)                           // norm / sample error words of this iteration
+            if (err_flags[i]) flags |= 8;
         res->flags |= flags;
         res->next_token = status == 0 ? tok : -1;
         if (status == 0) seq[n + 1] = tok;
@@ -680,7 +683,17 @@ extern "C" int sd_resample(const float *p_hist, const float *q_hist, long ld, in
     SD_REQUIRE(p_hist && q_hist && seq && res && V > 0, "sd_resample: bad arguments");
     (void)L;
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p_hist, q_hist, ld, V, seq, gamma,
-                       exp_noise, philox_seed, draw_index, res, seq_len);
+                       exp_noise, philox_seed, draw_index, res, seq_len, (const int *)nullptr, 0);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// internal: the same with the iteration's error words folded into res->flags bit3 (used by sd_spec_iteration)
+int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
+                            uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res, const int *err_flags,
+                            int n_err, hipStream_t st) {
+    hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, gamma,
+                       (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }

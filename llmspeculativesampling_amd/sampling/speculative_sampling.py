@@ -71,6 +71,11 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
     ld = q_hist.stride(0)
     st = _stream()
 
+    if getattr(noise, "on_device", False) and not verbose:
+        return _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos_token_id, T, gamma,
+                                   temperature, top_k, top_p, random_seed, details, noise, res_dev, res_host, tok_host,
+                                   _event_logs)
+
     approx_time = target_time = other_time = 0
     approx_calls = target_calls = 0
     acc_rate, acc_len = [], []
@@ -176,5 +181,103 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
             "target_model_time": target.forward_time_dict["_model_time"],
             "target_pre_cache_time": target.forward_time_dict["prepare_cache_time"],
             "target_post_prob_time": target.forward_time_dict["norm_prob_time"],
+        }
+    return out
+
+
+def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos_token_id, T, gamma, temperature,
+                        top_k, top_p, random_seed, details, noise, res_dev, res_host, tok_host, timing_log):
+    """Device-RNG mode: every iteration is ONE call into libspecdec (sd_spec_iteration) that enqueues the gamma draft
+    steps, the target forward, the accept scan and the resample; the host waits on the stream once per iteration and
+    reads 144 + 4*(gamma+2) bytes from pinned memory.  Same loop semantics as the Python-orchestrated path above
+    (reference speculative_sampling.py:1934-2046)."""
+    dev = target._model.device
+    V = target._model.cfg.vocab_size
+    seq_len0 = prefix.shape[1]
+    err_words = torch.zeros(3 * gamma + 1, dtype=torch.int32, device=dev)
+    sp = C.c_void_p()
+    check(lib.sd_spec_create(draft._session.handle, target._session.handle, gamma, float(temperature), int(top_k or 0),
+                             float(top_p or 0.0), seq32.data_ptr(), draft._probs.data_ptr(), target._probs.data_ptr(),
+                             draft._probs.stride(0), draft._session.logits.data_ptr(), draft._session.logits.stride(0),
+                             target._session.logits.data_ptr(), target._session.logits.stride(0), err_words.data_ptr(),
+                             res_dev.data_ptr(), C.byref(sp)), "sd_spec_create")
+    if timing_log is not None:
+        check(lib.sd_spec_timing(sp, 1), "sd_spec_timing")
+    r_const = None
+    if random_seed:
+        g = torch.Generator().manual_seed(int(random_seed))
+        r_const = torch.rand(1, generator=g).repeat(gamma).to(dev)
+    st = _stream()
+    stream_obj = torch.cuda.current_stream()
+    approx_time = target_time = other_time = 0
+    calls = 0
+    acc_rate, acc_len = [], []
+    out_tokens = host_seq
+    draft_len = target_len = 0
+    res_view = res_host.numpy()
+    dms, tms = C.c_float(0), C.c_float(0)
+    try:
+        while len(host_seq) < T:
+            tick = process_time_ns()
+            L = len(host_seq)
+            d_draft = noise.next_draws(gamma)
+            noise.next_draws(1)                          # the discarded target sample still advances the stream
+            seed_draft = noise.seed
+            if random_seed:
+                noise.reseed(random_seed)
+                d_scan = 0
+            else:
+                d_scan = noise.next_draws(gamma)
+            d_res = noise.next_draws(1)
+            check(lib.sd_spec_iteration(sp, L, draft_len, target_len, seed_draft, d_draft, noise.seed, d_scan, d_res,
+                                        r_const.data_ptr() if r_const is not None else None, res_host.data_ptr(),
+                                        tok_host.data_ptr(), st), "sd_spec_iteration")
+            stream_obj.synchronize()
+            res = SdAcceptResult.from_buffer_copy(res_view.tobytes())
+            if res.flags & 2:
+                raise RuntimeError("prob error")
+            if res.flags & 8:
+                if bool(err_words[gamma:2 * gamma].any()):
+                    raise RuntimeError("prob error")
+                raise RuntimeError("norm logits error")
+            if timing_log is not None:
+                check(lib.sd_spec_last_times(sp, C.byref(dms), C.byref(tms)), "sd_spec_last_times")
+                timing_log["draft_ms"].append(dms.value)
+                timing_log["target"].append((tms.value, L + gamma - target_len, L + gamma))
+            calls += 1
+            l, n, t = res.n_accepted, res.n, res.next_token
+            for i in range(gamma):
+                acc_rate.append(min(1.0, float(res.p_at[i]) / float(res.q_at[i])))
+            acc_len.append(l)
+            assert n >= L - 1, f"n {n}, prefix_len {L}"
+            host_seq = host_seq + tok_host[:l].tolist() + [t]
+            draft_len = min(L + gamma - 1, n + 1)        # rollback(n+1) of both caches (:2000, :2015/2023)
+            target_len = n + 1
+            out_tokens = host_seq
+            eos_total = sum(1 for x in host_seq if x == eos_token_id)
+            if eos_total > ori_eos_cnt:
+                seen, cut = 0, len(host_seq)
+                for idx, x in enumerate(host_seq):
+                    if x == eos_token_id:
+                        seen += 1
+                        if seen == ori_eos_cnt + 1:
+                            cut = idx + 1
+                            break
+                out_tokens = host_seq[:cut]
+                break
+            other_time += process_time_ns() - tick
+    except Exception as e:
+        print(e)
+        lib.sd_spec_destroy(sp)
+        raise RuntimeError("s")
+    lib.sd_spec_destroy(sp)
+    draft._session.cache_len, target._session.cache_len = draft_len, target_len
+    out = torch.tensor([out_tokens], dtype=torch.int64, device=prefix.device)
+    if details:
+        return out, {
+            "approx_time": approx_time, "target_time": target_time, "other_time": other_time,
+            "acc_len": acc_len, "acc_rate": np.mean(acc_rate),
+            "target_call_times": calls, "approx_call_times": calls,
+            "target_model_time": 0, "target_pre_cache_time": 0, "target_post_prob_time": 0,
         }
     return out

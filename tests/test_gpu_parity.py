@@ -475,3 +475,24 @@ def test_speculative_bf16_statistics_vs_oracle(hip):
     assert common >= 24 + 8, (common, w, g)                 # identical well past the prompt
     assert abs(float(np.mean(gd["acc_len"])) - float(np.mean(wd["acc_len"]))) <= 1.0
     assert abs(float(gd["acc_rate"]) - float(wd["acc_rate"])) <= 0.15
+
+
+def test_native_iteration_matches_python_loop(hip, capsys):
+    """sd_spec_iteration (one native call per iteration, device Philox) == the Python-orchestrated loop with the
+    same Philox seed (verbose=True keeps the Python path), incl. the random_seed quirk and an all-accept pair."""
+    from llmspeculativesampling_amd.synth import perturb_state_dict
+    cfg = load_config("tiny-llama-target")
+    dsd = make_state_dict(cfg, 11)
+    prompt = torch.from_numpy(np.random.default_rng(2).integers(3, cfg.vocab_size, size=(1, 70))).cuda()   # > 64: chunked prefill
+    for tsd, kw in ((perturb_state_dict(dsd, 12, 0.12), dict(top_k=20, top_p=0.9)),
+                    (perturb_state_dict(dsd, 12, 0.12), dict(top_k=20, top_p=0.9, random_seed=42)),
+                    (dsd, dict(top_k=10, top_p=0.0, gamma=3))):
+        dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.float32)
+        tm = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.float32)
+        a, da = hip.S.speculative_sampling(prompt, dm, tm, 2, None, 30, details=True, rng=hip.noise.DeviceNoise(77), **kw)
+        b, db = hip.S.speculative_sampling(prompt, dm, tm, 2, None, 30, details=True, rng=hip.noise.DeviceNoise(77),
+                                           verbose=True, **kw)
+        capsys.readouterr()
+        assert torch.equal(a, b)
+        assert da["acc_len"] == db["acc_len"] and da["target_call_times"] == db["target_call_times"]
+        assert abs(float(da["acc_rate"]) - float(db["acc_rate"])) < 1e-9

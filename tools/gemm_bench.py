@@ -57,5 +57,5 @@ if __name__ == "__main__":
         N, K = SHAPES[n]
         for u in (None, 512, 768, 1024, 1280, 2048, 2560, 4096):
             bench(n, N, K, units=u)
-    for M in (1, 2, 5, 16, 32, 64):
+    for M in (1, 5, 16, 17, 32, 48, 64):
         bench("gate_up", *SHAPES["gate_up"], M=M)
