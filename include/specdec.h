@@ -52,7 +52,11 @@ const char *sd_last_error(void);
  * reference then casts with .float(), modeling_llama.py:869-870). */
 int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
                   float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
-                  void *stream);
+                  void *workspace, void *stream);
+/* workspace (device, sd_norm_workspace_bytes(rows) bytes, may be NULL): with it and 1 <= top_k <= 64 each row is first
+ * cut over 16 workgroups that extract the candidates above a safe threshold, so one 128 KiB row is not limited by what a
+ * single CU can pull (~25 GB/s); without it one workgroup does everything.  Results are identical either way. */
+size_t sd_norm_workspace_bytes(int rows);
 
 /* One draft / autoregressive step's tail fused: norm_logits of ONE row followed by sample() on it
  * (kvcache_model.py:235-236 + :283), a single launch.  Writes the probability row (the accept scan and
@@ -60,7 +64,8 @@ int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temper
  * Philox only the surviving tokens draw a variate.  sample_err as sd_sample's err_flag. */
 int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
                    int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
-                   uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *stream);
+                   uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *workspace,
+                   void *stream);
 
 /* sample (utils.py:213-233) for num_samples == 1: argmax_i probs[i] / noise[i] (first index wins
  * ties), then the "< 1e-9 -> argmax(probs)" fix-up.  exp_noise is a device row of Exp(1) variates
@@ -199,7 +204,7 @@ typedef struct sd_spec sd_spec;
 int sd_spec_create(sd_session *draft, sd_session *target, int gamma, float temperature, int top_k, float top_p,
                    int32_t *seq, float *q_hist, float *p_hist, long ld, float *draft_logits, long ld_draft_logits,
                    float *target_logits, long ld_target_logits, int *err_words, sd_accept_result *res_dev,
-                   sd_spec **out);
+                   void *norm_workspace /* sd_norm_workspace_bytes(gamma+1) bytes or NULL */, sd_spec **out);
 int sd_spec_destroy(sd_spec *sp);
 int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_t seed_draft, uint64_t draw_draft0,
                       uint64_t seed_accept, uint64_t draw_scan0, uint64_t draw_resample, const float *r_const,

@@ -49,8 +49,9 @@ _F, _I, _L, _U64 = C.c_float, C.c_int, C.c_long, C.c_uint64
 SYMBOLS = [
     ("sd_version", _I, []),
     ("sd_last_error", C.c_char_p, []),
-    ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP]),
-    ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP, _VP]),
+    ("sd_norm_workspace_bytes", C.c_size_t, [_I]),
+    ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),
@@ -64,7 +65,7 @@ SYMBOLS = [
     ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),
     ("sd_session_destroy", _I, [_VP]),
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
-    ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, C.POINTER(_VP)]),
+    ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
     ("sd_spec_destroy", _I, [_VP]),
     ("sd_spec_iteration", _I, [_VP, _I, _I, _I, _U64, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_spec_timing", _I, [_VP, _I]),

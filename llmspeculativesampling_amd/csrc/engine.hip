@@ -571,6 +571,7 @@ struct sd_spec {
     long ld_dl, ld_tl;
     int *err;                    // device ints: [0..gamma) norm err of draft rows, [gamma..2gamma) sample err, [2gamma..3gamma+1) target rows
     sd_accept_result *res_dev;
+    void *norm_ws;               // sd_norm_workspace_bytes(gamma+1) bytes, may be NULL
     hipEvent_t ev[4];
     int timing;
 };
@@ -578,7 +579,7 @@ struct sd_spec {
 extern "C" int sd_spec_create(sd_session *draft, sd_session *target, int gamma, float temperature, int top_k,
                               float top_p, int32_t *seq, float *q_hist, float *p_hist, long ld, float *draft_logits,
                               long ld_draft_logits, float *target_logits, long ld_target_logits, int *err_words,
-                              sd_accept_result *res_dev, sd_spec **out) {
+                              sd_accept_result *res_dev, void *norm_workspace, sd_spec **out) {
     SD_REQUIRE(draft && target && seq && q_hist && p_hist && draft_logits && target_logits && err_words && res_dev && out,
                "sd_spec_create: null argument");
     SD_REQUIRE(gamma >= 1 && gamma <= 16, "sd_spec_create: gamma must be in 1..16");
@@ -588,7 +589,7 @@ extern "C" int sd_spec_create(sd_session *draft, sd_session *target, int gamma, 
     sp->draft = draft; sp->target = target; sp->gamma = gamma; sp->temperature = temperature; sp->top_k = top_k;
     sp->top_p = top_p; sp->V = draft->m->cfg.vocab; sp->seq = seq; sp->q_hist = q_hist; sp->p_hist = p_hist; sp->ld = ld;
     sp->draft_logits = draft_logits; sp->ld_dl = ld_draft_logits; sp->target_logits = target_logits; sp->ld_tl = ld_target_logits;
-    sp->err = err_words; sp->res_dev = res_dev; sp->timing = 0;
+    sp->err = err_words; sp->res_dev = res_dev; sp->norm_ws = norm_workspace; sp->timing = 0;
     for (int i = 0; i < 4; ++i) SD_HIP_CHECK(hipEventCreate(&sp->ev[i]));
     *out = sp;
     return SD_OK;
@@ -617,10 +618,11 @@ extern "C" int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms
 
 extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
                               int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
-                              uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *stream);
+                              uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *workspace,
+                              void *stream);
 extern "C" int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
                              float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
-                             void *stream);
+                             void *workspace, void *stream);
 extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld, const int32_t *seq, int L, int gamma,
                               const float *r, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *out,
                               void *stream);
@@ -660,7 +662,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         draft_len = upto;
         if ((rc = sd_norm_sample(sp->draft_logits, V, sp->temperature, sp->top_k, sp->top_p, 0,
                                  sp->q_hist + (size_t)(upto - 1) * sp->ld, sp->err + i, nullptr, seed_draft,
-                                 draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, stream)) != SD_OK)
+                                 draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws, stream)) != SD_OK)
             return rc;
     }
     if (sp->timing) { SD_HIP_CHECK(hipEventRecord(sp->ev[1], st)); SD_HIP_CHECK(hipEventRecord(sp->ev[2], st)); }
@@ -670,7 +672,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         const int rows = std::min(upto - target_len, g + 1);
         if ((rc = feed_rows(sp->target, sp->seq, target_len, upto, rows, sp->target_logits, sp->ld_tl, stream)) != SD_OK) return rc;
         if ((rc = sd_norm_probs(sp->target_logits, rows, V, sp->ld_tl, sp->temperature, sp->top_k, sp->top_p, 0,
-                                sp->p_hist + (size_t)(upto - rows) * sp->ld, sp->ld, sp->err + 2 * g, stream)) != SD_OK)
+                                sp->p_hist + (size_t)(upto - rows) * sp->ld, sp->ld, sp->err + 2 * g, sp->norm_ws, stream)) != SD_OK)
             return rc;
     }
     if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[3], st));

@@ -8,6 +8,13 @@
 // LDS (V*4 B <= 128 KiB for Llama's V = 32000) and every later pass reads LDS, not HBM.
 #include "common.h"
 
+#ifdef SD_STAMPS
+__device__ long long g_stamps[32];
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 #define NT 1024            // threads per row workgroup
 #define MAX_CAND 1024      // survivors handled by the in-LDS exact sort
 #define LDS_ROW_LIMIT (35 * 1024)   // floats; above this the row is re-read from L2 instead of LDS
@@ -21,6 +28,10 @@ __device__ __forceinline__ uint32_t fkey(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+__device__ __forceinline__ float funkey(uint32_t k) {           // inverse of fkey (the key carries the value exactly)
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __device__ __forceinline__ int block_sum_i(int v, int *sh) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -29,8 +40,8 @@ __device__ __forceinline__ int block_sum_i(int v, int *sh) {
     if (lane == 0) sh[w] = v;
     __syncthreads();
     int r = 0;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sh[i];
     return r;
 }
 
@@ -41,8 +52,8 @@ __device__ __forceinline__ double block_sum_d(double v, double *sh) {
     if (lane == 0) sh[w] = v;
     __syncthreads();
     double r = 0.0;
-#pragma unroll
-    for (int i = 0; i < NT / 64; ++i) r += sh[i];
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += sh[i];
     return r;
 }
 
@@ -128,7 +139,16 @@ __device__ __forceinline__ void rank_sort(NormShared &S, int n) {
         const uint32_t k = S.ckey[tid];
         const int id = S.cidx[tid];
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {                              // 16 LDS reads in flight per step (broadcast reads)
+            uint32_t kj[8];
+            int ij[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { kj[u] = S.ckey[j + u]; ij[u] = S.cidx[j + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (kj[u] > k) || (kj[u] == k && ij[u] < id);
+        }
+        for (; j < n; ++j) {
             const uint32_t kj = S.ckey[j];
             rank += (kj > k) || (kj == k && S.cidx[j] < id);
         }
@@ -136,6 +156,95 @@ __device__ __forceinline__ void rank_sort(NormShared &S, int n) {
         S.sidx[rank] = id;
     }
     __syncthreads();
+}
+
+// ---- multi-workgroup candidate extraction (fast path, 1 <= top_k <= 64) -------------------------------
+// One workgroup can pull only ~25 GB/s from L2/HBM, so a 128 KiB row costs ~20 us on a single CU.  The row is
+// therefore cut into NB_SPLIT chunks: each workgroup normalises its chunk's logits (/temperature), zero-fills its
+// part of the output row and keeps the few elements above a local threshold that is guaranteed to lie at or below
+// the chunk's k-th largest value (so every element >= the row's k-th largest survives).  norm_probs_kernel then
+// works on <= 1024 candidates and scatters the <= k non-zero probabilities.
+#define NB_SPLIT 16
+#define CAND_CAP 192
+#define CAND_MAXIT 4
+struct CandHdr { int count; int bad; float maxv; int pad; };
+struct CandRow { CandHdr hdr[NB_SPLIT]; uint2 cand[NB_SPLIT][CAND_CAP]; };
+
+__global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict__ logits, long ld_in, int V,
+                                                       float temperature, int top_k, int bf16_round,
+                                                       float *__restrict__ out, long ld_out, CandRow *__restrict__ ws) {
+    __shared__ uint32_t wk_sh[4];
+    __shared__ uint32_t mk_sh[256];
+    __shared__ int cnt_sh;
+    __shared__ uint2 cand_sh[CAND_CAP];
+    __shared__ float redf[16];
+    __shared__ int redi[16];
+    const int row = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float4 *x4 = reinterpret_cast<const float4 *>(logits + (size_t)row * ld_in);
+    float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row * ld_out);
+    const int V4 = V >> 2, C4 = (V4 + NB_SPLIT - 1) / NB_SPLIT;
+    const int lo = b * C4, hi = min(V4, lo + C4);
+    float4 z[CAND_MAXIT];
+    float mt = -INFINITY;
+    int bad = 0;
+#pragma unroll
+    for (int u = 0; u < CAND_MAXIT; ++u) {
+        const int i4 = lo + tid + u * 256;
+        if (i4 < hi) z[u] = x4[i4];
+    }
+#pragma unroll
+    for (int u = 0; u < CAND_MAXIT; ++u) {
+        const int i4 = lo + tid + u * 256;
+        if (i4 < hi) {
+            float4 v = z[u];
+            if (bf16_round) { v.x = (float)(bf16_t)v.x; v.y = (float)(bf16_t)v.y; v.z = (float)(bf16_t)v.z; v.w = (float)(bf16_t)v.w; }
+            v.x = v.x / temperature; v.y = v.y / temperature; v.z = v.z / temperature; v.w = v.w / temperature;
+            z[u] = v;
+            bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            mt = fmaxf(fmaxf(mt, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            o4[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // threshold = the k-th largest of the workgroup's 256 per-thread maxima (rank counting through LDS): at least k
+    // elements of the chunk lie at or above it, and only ~1 % of the chunk does
+    const int k = min(top_k, V);
+    const uint32_t mk = fkey(mt);
+    mk_sh[tid] = mk;
+    if (tid == 0) { cnt_sh = 0; wk_sh[0] = 0u; }
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < 256; j += 8) {
+        uint32_t kj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kj[u] = mk_sh[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (kj[u] > mk) || (kj[u] == mk && (j + u) < tid);
+    }
+    if (rank == k - 1) wk_sh[0] = mk;
+    __syncthreads();
+    const uint32_t t0 = wk_sh[0];
+#pragma unroll
+    for (int u = 0; u < CAND_MAXIT; ++u) {
+        const int i4 = lo + tid + u * 256;
+        if (i4 < hi) {
+            const float e[4] = {z[u].x, z[u].y, z[u].z, z[u].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t kk = fkey(e[c]);
+                if (kk >= t0) {
+                    const int slot = atomicAdd(&cnt_sh, 1);
+                    if (slot < CAND_CAP) cand_sh[slot] = make_uint2(kk, (uint32_t)(i4 * 4 + c));
+                }
+            }
+        }
+    }
+    const float bm = block_max(mt, redf);
+    bad = block_sum_i(bad, redi);
+    __syncthreads();
+    const int n = cnt_sh;
+    CandRow &R = ws[row];
+    if (tid == 0) { R.hdr[b].count = n; R.hdr[b].bad = bad; R.hdr[b].maxv = bm; }
+    for (int i = tid; i < min(n, CAND_CAP); i += 256) R.cand[b][i] = cand_sh[i];
 }
 
 // norm_logits (+ optionally the sample that follows it in the draft / autoregressive loops, utils.py:213-233).
@@ -148,7 +257,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                                                        int staged, float *__restrict__ out, long ld_out,
                                                        int *__restrict__ err, const float *__restrict__ noise,
                                                        uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
-                                                       int *__restrict__ samp_err) {
+                                                       int *__restrict__ samp_err, const CandRow *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NormShared &S = *reinterpret_cast<NormShared *>(smem);
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
@@ -162,11 +271,90 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         if (bf16_round) v = (float)(bf16_t)v;
         return v / temperature;                                   // utils.py:197
     };
-    auto Z = [&](int i) -> float { return staged ? zs[i] : load_z(i); };
-
-    // pass 0: stage, row max, NaN detection (16-byte loads, all of a thread's loads in flight at once)
-    float mt = -INFINITY;
+    STAMP(0);
+    // fast entry: norm_cand_kernel already cut the row down to a candidate list (and zero-filled the output row)
+    bool fast = false;
+    float m = 0.f;
     int bad = 0;
+    if (ws) {
+        const CandRow &R = ws[row];
+        // the 16 chunk headers are fetched by 16 lanes at once (a serial loop would pay 16 L2 round trips)
+        if (tid < NB_SPLIT) {
+            S.cidx[tid] = R.hdr[tid].count;
+            S.sidx[tid] = R.hdr[tid].bad;
+            S.redf[tid] = R.hdr[tid].maxv;
+        }
+        __syncthreads();
+        int tot = 0, over = 0;
+        float mx = -INFINITY;
+        int cnts[NB_SPLIT];
+#pragma unroll
+        for (int b2 = 0; b2 < NB_SPLIT; ++b2) {
+            cnts[b2] = S.cidx[b2];
+            over |= (cnts[b2] > CAND_CAP);
+            tot += cnts[b2];
+            bad |= S.sidx[b2];
+            mx = fmaxf(mx, S.redf[b2]);
+        }
+        __syncthreads();
+        if (!over && tot <= MAX_CAND) {
+            // one global load per thread: locate (chunk, slot) of candidate `tid` from the 16 counts in registers
+            if (tid < tot) {
+                int base = 0, blk = 0, off = tid;
+#pragma unroll
+                for (int b2 = 0; b2 < NB_SPLIT; ++b2) {
+                    if (tid >= base && tid < base + cnts[b2]) { blk = b2; off = tid - base; }
+                    base += cnts[b2];
+                }
+                const uint2 e = R.cand[blk][off];
+                S.ckey[tid] = e.x;
+                S.cidx[tid] = (int)e.y;
+            }
+            if (tid == 0) { S.n_cand = tot; S.kept = 0; }
+            __syncthreads();
+            if (tot > 128 && top_k <= 64) {
+                // second-level prefilter on the gathered list (one candidate per thread): every chunk kept at least
+                // its own top-k, so the union is several hundred entries; the same rank-select trick cuts it to a
+                // few dozen before the O(n^2) stable sort
+                const uint32_t mk = tid < tot ? S.ckey[tid] : 0u;
+                const int k2 = min(top_k, V);
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) {
+                    const uint32_t kj = (uint32_t)__shfl((int)mk, j, 64);
+                    rank += (kj > mk) || (kj == mk && j < lane);
+                }
+                const unsigned long long hit = __ballot(rank == k2 - 1);
+                const uint32_t wk = (uint32_t)__shfl((int)mk, hit ? (int)(__ffsll((long long)hit) - 1) : 0, 64);
+                if (lane == 0) S.redu[wv] = wk;
+                __syncthreads();
+                uint32_t t1 = S.redu[0];
+#pragma unroll
+                for (int i = 1; i < NT / 64; ++i) t1 = max(t1, S.redu[i]);
+                if (tid < tot && mk >= t1) {
+                    const int slot = atomicAdd(&S.kept, 1);
+                    S.skey[slot] = mk;
+                    S.sidx[slot] = S.cidx[tid];
+                }
+                __syncthreads();
+                const int n2 = S.kept;
+                if (tid < n2) { S.ckey[tid] = S.skey[tid]; S.cidx[tid] = S.sidx[tid]; }
+                if (tid == 0) S.n_cand = n2;
+                __syncthreads();
+            }
+            fast = true;
+            m = mx;
+        } else {
+            bad = 0;
+        }
+    }
+    STAMP(1);
+    const bool use_lds = staged && !fast;
+    auto Z = [&](int i) -> float { return use_lds ? zs[i] : load_z(i); };
+
+    float mt = -INFINITY;
+    if (!fast) {
+    // pass 0: stage, row max, NaN detection (16-byte loads, all of a thread's loads in flight at once)
     if (staged && (V & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
         const int V4 = V >> 2;
         for (int i0 = tid; i0 < V4; i0 += NT * 8) {
@@ -200,8 +388,9 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             mt = fmaxf(mt, z);
         }
     }
-    const float m = block_max(mt, S.redf);
+    m = block_max(mt, S.redf);
     bad = block_sum_i(bad, S.redi);
+    }
     if (bad || m == INFINITY || m == -INFINITY) {                 // exp(log_softmax) would hold NaN (utils.py:203)
         for (int i = tid; i < V; i += NT) o[i] = __uint_as_float(0x7fc00000u);
         if (tid == 0) {
@@ -211,12 +400,22 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         return;
     }
 
+    STAMP(2);
     uint32_t kth = 0u;                                            // key >= 0 keeps everything
     bool have_list = false;                                       // skey/sidx hold a superset of the survivors, sorted
     int n_list = 0, n_surv = V;
     if (top_k > 0) {
         const int k = min(top_k, V);
-        if (k <= 64) {
+        if (fast) {
+            const int n = S.n_cand;
+            rank_sort(S, n);
+            kth = S.skey[k - 1];
+            int ns = k;
+            while (ns < n && S.skey[ns] == kth) ++ns;
+            n_surv = ns;
+            n_list = n;
+            have_list = true;
+        } else if (k <= 64) {
             // ---- prefilter: a threshold t0 with at least k elements above it.  Each wave takes the k-th
             // largest of its 64 per-thread maxima (rank counting over readlanes); t0 = the largest of those.
             const uint32_t mk = fkey(mt);
@@ -268,6 +467,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
     }
 
+    STAMP(3);
     // top-p (utils.py:170-178).  keep(i) <=> key_i > cut_key || (key_i == cut_key && i <= cut_idx)
     uint32_t cut_key = kth;
     int cut_idx = 0x7fffffff;
@@ -305,13 +505,13 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 int nf = n_surv;
                 while (nf > 1 && S.skey[nf - 1] <= neg_inf_key) --nf;
                 float denom = 0.f;                                // softmax denominator over the survivors
-                for (int i = 0; i < nf; ++i) denom += expf(Z(S.sidx[i]) - m);
+                for (int i = 0; i < nf; ++i) denom += expf(funkey(S.skey[i]) - m);
                 // torch.cumsum accumulates float32 inputs in double and rounds each prefix to float32
                 double cum = 0.0;
                 int kp = 0;
                 for (int i = 0; i < nf; ++i) {
                     if (i > 0 && (float)cum > top_p) break;       // shifted filter: the crossing token stays
-                    cum += (double)(expf(Z(S.sidx[i]) - m) / denom);
+                    cum += (double)(expf(funkey(S.skey[i]) - m) / denom);
                     kp = i + 1;
                 }
                 S.kept = kp;
@@ -385,39 +585,46 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
     }
 
+    STAMP(4);
     // probs = exp(log_softmax(filtered))  (utils.py:199), then optionally sample (utils.py:213-233)
     if (kept >= 0) {
         // list mode: the kept set is the first `kept` entries of the sorted candidate list
         if (tid == 0) {
             float sum = 0.f;
-            for (int i = 0; i < kept; ++i) sum += expf(Z(S.sidx[i]) - m);
+            for (int i = 0; i < kept; ++i) sum += expf(funkey(S.skey[i]) - m);
             S.lse = logf(sum);
         }
-        if ((V & 3) == 0 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+        if (fast) {
+            // norm_cand_kernel zero-filled the row
+        } else if ((V & 3) == 0 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
             for (int i4 = tid; i4 < (V >> 2); i4 += NT) reinterpret_cast<float4 *>(o)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             for (int i = tid; i < V; i += NT) o[i] = 0.0f;
         }
         __syncthreads();
         const float lse = S.lse;
-        if (tid < kept) o[S.sidx[tid]] = expf((Z(S.sidx[tid]) - m) - lse);
-        if (SAMPLE && tid == 0) {
-            // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and
-            // never win); first index wins ties; fix-up for a pick below 1e-9 (utils.py:228-230)
-            float best = -1.f;
-            int bi = 0x7fffffff;
-            float pbest = 0.f;
-            for (int i = 0; i < kept; ++i) {
-                const int id = S.sidx[i];
-                const float p = expf((Z(id) - m) - lse);
-                if (!(p > 0.f)) continue;
-                const float e = noise ? noise[id] : philox_exp(seed, draw, id);
-                const float r = p / e;
-                if (r > best || (r == best && id < bi)) { best = r; bi = id; pbest = p; }
+        if (tid < kept) o[S.sidx[tid]] = expf((funkey(S.skey[tid]) - m) - lse);
+        STAMP(5);
+        if (SAMPLE) {
+            // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and never
+            // win); first index wins ties; fix-up for a pick below 1e-9 (utils.py:228-230).  One lane per kept entry.
+            ArgMax br = {0.f, 0x7fffffff};
+            if (tid < kept) {
+                const int id = S.sidx[tid];
+                const float p = expf((funkey(S.skey[tid]) - m) - lse);
+                if (p > 0.f) br = {p / (noise ? noise[id] : philox_exp(seed, draw, id)), id};
             }
-            if (pbest < 1e-9f) bi = S.sidx[0];                    // argmax(probs): list head (lowest index among ties)
-            *tok_out = bi;
-            if (samp_err) *samp_err = 0;
+            ArgMax *sha = reinterpret_cast<ArgMax *>(S.ckey);
+            br = block_argmax(br, sha);
+            if (tid == 0) {
+                int tok = br.i;
+                float ptok = 0.f;
+                for (int i = 0; i < kept; ++i)
+                    if (S.sidx[i] == tok) ptok = expf((funkey(S.skey[i]) - m) - lse);
+                if (tok == 0x7fffffff || ptok < 1e-9f) tok = S.sidx[0];   // argmax(probs): list head (lowest index among ties)
+                *tok_out = tok;
+                if (samp_err) *samp_err = 0;
+            }
         }
     } else {
         float part = 0.f;
@@ -454,6 +661,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             }
         }
     }
+    STAMP(6);
     if (tid == 0 && err) err[row] = 0;
     (void)n_list;
 }
@@ -606,7 +814,8 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
-                       const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *stream) {
+                       const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
+                       void *stream) {
     const int staged = V <= LDS_ROW_LIMIT;
     const size_t base = (sizeof(NormShared) + 15) & ~size_t(15);
     const size_t lds = base + (staged ? (size_t)V * sizeof(float) : 0);
@@ -618,36 +827,49 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    // two-kernel fast path: the row is cut over NB_SPLIT workgroups first (see norm_cand_kernel)
+    CandRow *ws = nullptr;
+    if (workspace && top_k >= 1 && top_k <= 64 && V >= 4096 && (V & 3) == 0 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
+        ((V >> 2) + NB_SPLIT - 1) / NB_SPLIT <= 256 * CAND_MAXIT && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(probs_out) & 15) == 0) {
+        ws = static_cast<CandRow *>(workspace);
+        hipLaunchKernelGGL(norm_cand_kernel, dim3(NB_SPLIT, rows), dim3(256), 0, (hipStream_t)stream, logits, ld_in, V,
+                           temperature, top_k, bf16_round_logits, probs_out, ld_out, ws);
+        SD_LAUNCH_CHECK();
+    }
     if (do_sample)
         hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
-                           seed, draw, tok_out, samp_err);
+                           seed, draw, tok_out, samp_err, (const CandRow *)ws);
     else
         hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
-                           (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr);
+                           (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
+                           (const CandRow *)ws);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
 
+extern "C" size_t sd_norm_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandRow); }
+
 extern "C" int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
                              float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
-                             void *stream) {
+                             void *workspace, void *stream) {
     SD_REQUIRE(logits && probs_out && rows >= 0 && V > 0, "sd_norm_probs: bad arguments");
     SD_REQUIRE(temperature != 0.0f, "sd_norm_probs: temperature must be non-zero");
     if (rows == 0) return SD_OK;
     return launch_norm(logits, rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, probs_out, ld_out,
-                       err_flag, false, nullptr, 0, 0, nullptr, nullptr, stream);
+                       err_flag, false, nullptr, 0, 0, nullptr, nullptr, workspace, stream);
 }
 
 extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int top_k, float top_p,
                               int bf16_round_logits, float *probs_out, int *err_flag, const float *exp_noise,
                               uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err,
-                              void *stream) {
+                              void *workspace, void *stream) {
     SD_REQUIRE(logits && probs_out && tok_out && V > 0, "sd_norm_sample: bad arguments");
     SD_REQUIRE(temperature != 0.0f, "sd_norm_sample: temperature must be non-zero");
     return launch_norm(logits, 1, V, V, temperature, top_k, top_p, bf16_round_logits, probs_out, V, err_flag, true,
-                       exp_noise, philox_seed, draw_index, tok_out, sample_err, stream);
+                       exp_noise, philox_seed, draw_index, tok_out, sample_err, workspace, stream);
 }
 
 extern "C" int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,

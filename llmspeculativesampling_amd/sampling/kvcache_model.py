@@ -52,6 +52,7 @@ class KVCacheModel:
         self._probs = torch.zeros((self._session.max_seq, m.cfg.vocab_size), dtype=torch.float32, device=dev)
         self._err = torch.zeros(self._session.max_seq, dtype=torch.int32, device=dev)
         self._tok32 = torch.zeros(self._session.max_seq + 1, dtype=torch.int32, device=dev)
+        self._norm_ws = torch.empty(lib.sd_norm_workspace_bytes(self._session.max_rows), dtype=torch.uint8, device=dev)
 
     # -- attributes the reference exposes ---------------------------------------------------
     @property
@@ -95,7 +96,7 @@ class KVCacheModel:
             check(lib.sd_norm_probs(logits.data_ptr(), blk, V, logits.stride(0), float(self._temperature),
                                     int(self._top_k or 0), float(self._top_p or 0.0), 0,
                                     self._probs[end - blk].data_ptr(), self._probs.stride(0),
-                                    self._err[end - blk].data_ptr(), st), "sd_norm_probs")
+                                    self._err[end - blk].data_ptr(), self._norm_ws.data_ptr(), st), "sd_norm_probs")
             self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
             self.forward_time_dict["_model_time"] += t1 - t0
             t0 = process_time_ns()
@@ -129,7 +130,8 @@ class KVCacheModel:
             e_ptr, seed, draw = e.data_ptr(), 0, 0
         check(lib.sd_norm_sample(logits.data_ptr(), V, float(self._temperature), int(self._top_k or 0),
                                  float(self._top_p or 0.0), 0, self._probs[row].data_ptr(), self._err[row].data_ptr(),
-                                 e_ptr, seed, draw, seq32[upto].data_ptr(), samp_err.data_ptr(), _stream()),
+                                 e_ptr, seed, draw, seq32[upto].data_ptr(), samp_err.data_ptr(), self._norm_ws.data_ptr(),
+                                 _stream()),
               "sd_norm_sample")
         self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
         self.forward_time_dict["_model_time"] += t1 - t0

@@ -200,7 +200,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                              float(top_p or 0.0), seq32.data_ptr(), draft._probs.data_ptr(), target._probs.data_ptr(),
                              draft._probs.stride(0), draft._session.logits.data_ptr(), draft._session.logits.stride(0),
                              target._session.logits.data_ptr(), target._session.logits.stride(0), err_words.data_ptr(),
-                             res_dev.data_ptr(), C.byref(sp)), "sd_spec_create")
+                             res_dev.data_ptr(), target._norm_ws.data_ptr(), C.byref(sp)), "sd_spec_create")
     if timing_log is not None:
         check(lib.sd_spec_timing(sp, 1), "sd_spec_timing")
     r_const = None

@@ -25,9 +25,10 @@ def norm_logits(logits: torch.Tensor, temperature: float, top_k: float, top_p: f
     rows, V = x.shape
     out = torch.empty_like(x)
     err = torch.zeros(rows, dtype=torch.int32, device=x.device)
+    ws = torch.empty(lib.sd_norm_workspace_bytes(rows), dtype=torch.uint8, device=x.device)
     check(lib.sd_norm_probs(x.data_ptr(), rows, V, x.stride(0), float(temperature), int(top_k or 0),
-                            float(top_p or 0.0), 0, out.data_ptr(), out.stride(0), err.data_ptr(), _stream()),
-          "sd_norm_probs")
+                            float(top_p or 0.0), 0, out.data_ptr(), out.stride(0), err.data_ptr(), ws.data_ptr(),
+                            _stream()), "sd_norm_probs")
     if bool(err.any()):
         raise RuntimeError("norm logits error")
     return out.to(logits.dtype)

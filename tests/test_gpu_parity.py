@@ -392,10 +392,13 @@ def test_norm_sample_fused_matches_two_step(hip):
             out = torch.empty(V, dtype=torch.float32, device="cuda")
             tok = torch.zeros(1, dtype=torch.int32, device="cuda")
             err = torch.zeros(2, dtype=torch.int32, device="cuda")
-            hip.L.check(hip.lib.sd_norm_sample(x.data_ptr(), V, T, k, p, 0, out.data_ptr(), err[0].data_ptr(),
-                                               noise.data_ptr(), 0, 0, tok.data_ptr(), err[1].data_ptr(), _st()))
-            assert torch.equal(out, probs[0])
-            assert int(tok) == int(want) and not bool(err.any())
+            for ws in (None, torch.empty(hip.lib.sd_norm_workspace_bytes(1), dtype=torch.uint8, device="cuda")):
+                out.fill_(-1.0)
+                hip.L.check(hip.lib.sd_norm_sample(x.data_ptr(), V, T, k, p, 0, out.data_ptr(), err[0].data_ptr(),
+                                                   noise.data_ptr(), 0, 0, tok.data_ptr(), err[1].data_ptr(),
+                                                   ws.data_ptr() if ws is not None else None, _st()))
+                assert torch.equal(out, probs[0])          # one-workgroup and 16-workgroup paths agree bit for bit
+                assert int(tok) == int(want) and not bool(err.any())
             ref = oracle.sample(oracle.norm_logits(x.cpu(), T, k, p), oracle.RecordedNoise([("exp", noise.cpu()[None])]))
             assert int(tok) == int(ref)
 

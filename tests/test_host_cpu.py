@@ -40,10 +40,10 @@ def test_argument_errors_do_not_need_a_gpu():
     import ctypes as C
     from llmspeculativesampling_amd import _lib
     with pytest.raises(ValueError):
-        _lib.check(_lib.lib.sd_norm_probs(None, 1, 8, 8, 1.0, 0, 0.0, 0, None, 8, None, None), "sd_norm_probs")
+        _lib.check(_lib.lib.sd_norm_probs(None, 1, 8, 8, 1.0, 0, 0.0, 0, None, 8, None, None, None), "sd_norm_probs")
     buf = (C.c_float * 8)()
     with pytest.raises(ValueError, match="temperature"):
-        _lib.check(_lib.lib.sd_norm_probs(C.addressof(buf), 1, 8, 8, 0.0, 0, 0.0, 0, C.addressof(buf), 8, None, None),
+        _lib.check(_lib.lib.sd_norm_probs(C.addressof(buf), 1, 8, 8, 0.0, 0, 0.0, 0, C.addressof(buf), 8, None, None, None),
                    "sd_norm_probs")
     with pytest.raises(ValueError, match="N % 16"):
         _lib.check(_lib.lib.sd_pack_weight_bf16(C.addressof(buf), C.addressof(buf), 8, 32, None), "sd_pack_weight_bf16")
