@@ -499,3 +499,17 @@ def test_native_iteration_matches_python_loop(hip, capsys):
         assert torch.equal(a, b)
         assert da["acc_len"] == db["acc_len"] and da["target_call_times"] == db["target_call_times"]
         assert abs(float(da["acc_rate"]) - float(db["acc_rate"])) < 1e-9
+
+
+def test_get_score_matches_oracle(hip):
+    """evaluation.py:109-132 get_score (the harness's untimed quality proxy) through the engine vs torch-CPU."""
+    from llmspeculativesampling_amd.quality import get_score
+    cfg = load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 12)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    out = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 90)))     # > 64 rows: chunked
+    got = float(get_score(out.cuda(), m, 20))
+    lg = oracle.RefCausalLM(cfg, sd)(out).logits[:, :-1, :]
+    lp = torch.gather(torch.log_softmax(lg, -1), -1, out[:, 1:, None])
+    want = float(lp[:, 19:, :].mean())
+    assert abs(got - want) < 1e-4
