@@ -191,6 +191,19 @@ int sd_session_destroy(sd_session *s);
 int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
                        float *logits_out, long ld_logits, void *stream);
 
+/* Stream-batched forward: the new rows of up to 16 independent sequences share ONE pass over the
+ * weights (same bytes streamed, n_items times the tokens).  Each item names its own session (KV arena), its token
+ * buffer `seq` (device int32 indexed by ABSOLUTE position: the rows read seq[pos0 .. pos0+n_new)), its cache length
+ * pos0, its number of new rows and how many of its last rows need logits.  Activations use items[0].session's
+ * scratch (total rows <= its max_rows, <= 64); all sessions must belong to the same model.  Logit rows come out packed
+ * in item order into logits_out.  sd_session_forward is the one-item case of this call. */
+typedef struct {
+    sd_session *session;
+    const int32_t *seq;
+    int32_t pos0, n_new, n_logits;
+} sd_batch_item;
+int sd_batch_forward(const sd_batch_item *items, int n_items, float *logits_out, long ld_logits, void *stream);
+
 /* One whole speculative iteration enqueued natively (device-RNG mode), reference speculative_sampling.py:1934-2031:
  * gamma x (draft forward over the uncached rows + sd_norm_sample straight into seq[]), one target forward over its
  * uncached rows + sd_norm_probs of the last gamma+1, sd_accept_scan, residual / bonus sample, then async copies of

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-c", os.path.join(CSRC, src), "-o", obj] + os.environ.get("SD_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -24,6 +24,11 @@ class SdAcceptResult(C.Structure):
                 ("p_at", C.c_float * 16), ("q_at", C.c_float * 16)]
 
 
+class SdBatchItem(C.Structure):
+    _fields_ = [("session", C.c_void_p), ("seq", C.c_void_p), ("pos0", C.c_int32), ("n_new", C.c_int32),
+                ("n_logits", C.c_int32)]
+
+
 class SdModelConfig(C.Structure):
     _fields_ = [("arch", C.c_int32), ("dtype", C.c_int32), ("vocab", C.c_int32), ("hidden", C.c_int32),
                 ("inter", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
@@ -65,6 +70,7 @@ SYMBOLS = [
     ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),
     ("sd_session_destroy", _I, [_VP]),
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
+    ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),
     ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
     ("sd_spec_destroy", _I, [_VP]),
     ("sd_spec_iteration", _I, [_VP, _I, _I, _I, _U64, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP]),

@@ -310,7 +310,8 @@ static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, 
 }
 
 // X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> split-K slabs in s->part
-static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st) {
+static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st,
+                    const RowTab *xtab = nullptr) {
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
     if (c.dtype == SD_BF16) {
@@ -319,13 +320,15 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
         GemmEpi e = {};
+        if (xtab) { e.use_xmap = 1; e.tab = *xtab; }
         const int rc = dispatch_gemm_bf16<EPI_PART>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
         if (rc != SD_OK) return rc;
         go->S = S;
         go->stride_s = (size_t)Mpad * N;
     } else {
+        RowTab none = {};
         hipLaunchKernelGGL(gemm_f32_simple, dim3((N + 3) / 4), dim3(256), 0, st, (const float *)W, (const float *)X,
-                           s->part, M, N, K);
+                           s->part, M, N, K, xtab ? *xtab : none, xtab ? 1 : 0);
         go->S = 1;
         go->stride_s = (size_t)M * N;
     }
@@ -346,10 +349,9 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
 }
 
 template <typename T, int D>
-static void launch_attn(sd_session *s, const T *q, const T *k, const T *v, T *out, int n_new, int pos0,
-                        hipStream_t st) {
+static void launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
-    const int s_cap = (int)align_up(pos0 + n_new, 64);
+    const int s_cap = (int)align_up(s_max, 64);
     const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
     static bool attr = false;
     if (!attr) {
@@ -357,14 +359,14 @@ static void launch_attn(sd_session *s, const T *q, const T *k, const T *v, T *ou
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, (n_new + ATT_TQ - 1) / ATT_TQ), dim3(256), lds, st, q, k,
-                       v, out, n_new, pos0, s->max_seq, c.n_heads, c.n_kv_heads, c.arch,
-                       1.0f / sqrtf((float)c.head_dim), s_cap);
+    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, tab.n_groups), dim3(256), lds, st, q, tab, layer, out,
+                       c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap);
 }
 
 template <typename T>
-static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits, float *logits_out,
-                        long ld_logits, hipStream_t st) {
+static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits,
+                        hipStream_t st) {
+    const int n_new = tab.n_rows, n_logits = tab.n_logit_rows;
     sd_model *m = s->m;
     const sd_model_config &c = m->cfg;
     const int H = c.hidden, D = c.head_dim, I = c.inter, L = c.n_layers, ED = embed_dim(c);
@@ -374,7 +376,6 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     const bool fused = c.dtype == SD_BF16 && c.fused_layout != 0;
     T *x = (T *)s->x, *h = (T *)s->h, *qb = (T *)s->qbuf, *at = (T *)s->attn, *ac = (T *)s->act, *eb = (T *)s->ebuf;
     const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
-    const size_t layer_kv = (size_t)2 * c.n_kv_heads * s->max_seq * D;      // elements per layer
     const int pos_off = 2;                                                   // OPT offset (modeling_opt.py:104)
     const int rn_threads = (int)std::min<size_t>(1024, std::max<size_t>(64, align_up(H / 4, 64)));
     GemmOut go;
@@ -383,20 +384,20 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     // ---- embeddings
     if (llama || ED == H) {
         ProfScope ps(s, PC_EMBED, st);
-        hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tokens, (const T *)m->w.embed, H,
-                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos0, pos_off, x);
+        hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, H,
+                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x);
         SD_LAUNCH_CHECK();
     } else {
         {
             ProfScope ps(s, PC_EMBED, st);
-            hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tokens, (const T *)m->w.embed, ED,
-                               (const T *)nullptr, 0, 0, eb);
+            hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, ED,
+                               (const T *)nullptr, 0, eb);
             SD_LAUNCH_CHECK();
         }
         if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
         ProfScope ps(s, PC_EMBED, st);
         hipLaunchKernelGGL((reduce_addpos_kernel<T>), dim3(n_new), dim3(256), 0, st, s->part, go.S, go.stride_s, H,
-                           (const T *)m->w.pos_embed, pos0, pos_off, x);
+                           (const T *)m->w.pos_embed, tab, pos_off, x);
         SD_LAUNCH_CHECK();
     }
     // ---- first pre-norm
@@ -410,15 +411,12 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     }
 
     for (int l = 0; l < L; ++l) {
-        T *karena = (T *)s->kv + (size_t)l * layer_kv;
-        T *varena = karena + (size_t)c.n_kv_heads * s->max_seq * D;
         // qkv projection -> rope / scale -> q buffer + in-place KV append
         if (fused) {
             GemmEpi e = {};
             e.out = (bf16_t *)qb; e.bias = (const bf16_t *)m->bqkv[l];
-            e.karena = (bf16_t *)karena; e.varena = (bf16_t *)varena;
             e.cos_t = (const bf16_t *)m->w.rope_cos; e.sin_t = (const bf16_t *)m->w.rope_sin;
-            e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.pos0 = pos0; e.max_seq = s->max_seq;
+            e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.layer = l; e.tab = tab;
             e.q_scale = 1.0f / sqrtf((float)D);
             rc = llama ? run_gemm_fused<EPI_QKV_ROPE>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st)
                        : run_gemm_fused<EPI_QKV_PLAIN>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st);
@@ -429,17 +427,16 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
             hipLaunchKernelGGL((qkv_epilogue_kernel<T>), dim3(n_new, c.n_heads + 2 * c.n_kv_heads),
                                dim3(std::max(D / 2, 64)), 0, st, s->part, go.S, go.stride_s, qkv_cols(c),
                                (const T *)m->bqkv[l], (const T *)m->w.rope_cos, (const T *)m->w.rope_sin, c.arch,
-                               1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, pos0, s->max_seq, qb, karena,
-                               varena);
+                               1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb);
             SD_LAUNCH_CHECK();
         }
         {
             ProfScope ps(s, PC_ATTN, st);
             switch (D) {
-                case 16: launch_attn<T, 16>(s, qb, karena, varena, at, n_new, pos0, st); break;
-                case 32: launch_attn<T, 32>(s, qb, karena, varena, at, n_new, pos0, st); break;
-                case 64: launch_attn<T, 64>(s, qb, karena, varena, at, n_new, pos0, st); break;
-                default: launch_attn<T, 128>(s, qb, karena, varena, at, n_new, pos0, st); break;
+                case 16: launch_attn<T, 16>(s, qb, tab, l, at, s_max, st); break;
+                case 32: launch_attn<T, 32>(s, qb, tab, l, at, s_max, st); break;
+                case 64: launch_attn<T, 64>(s, qb, tab, l, at, s_max, st); break;
+                default: launch_attn<T, 128>(s, qb, tab, l, at, s_max, st); break;
             }
             SD_LAUNCH_CHECK();
         }
@@ -487,16 +484,19 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     }
 
     if (n_logits > 0) {
-        const T *hl = h + (size_t)(n_new - n_logits) * H;       // only the last rows are ever read
+        // only the rows tab.xmap lists feed the head (the last rows of each stream)
+        const T *hl = h;
+        const RowTab *xt = &tab;
         if (ED != H) {                                          // OPT project_out (modeling_opt.py:744-745)
-            if ((rc = run_gemm(s, m->w.project_out, hl, n_logits, ED, H, &go, st)) != SD_OK) return rc;
+            if ((rc = run_gemm(s, m->w.project_out, hl, n_logits, ED, H, &go, st, xt)) != SD_OK) return rc;
+            xt = nullptr;
             ProfScope ps(s, PC_LOGITS, st);
             hipLaunchKernelGGL((reduce_rows_kernel<T>), dim3((ED + 255) / 256, n_logits), dim3(256), 0, st, s->part,
                                go.S, go.stride_s, ED, eb);
             SD_LAUNCH_CHECK();
             hl = eb;
         }
-        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st)) != SD_OK) return rc;
+        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
         ProfScope ps(s, PC_LOGITS, st);
         hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
                            go.stride_s, c.vocab, c.logits_bf16_round || (!llama && c.dtype == SD_BF16), logits_out,
@@ -506,20 +506,92 @@ static int forward_impl(sd_session *s, const int32_t *tokens, int n_new, int pos
     return SD_OK;
 }
 
+// fill the attention groups and the lm_head row map of a table whose rows are already laid out stream by stream
+static void finish_table(RowTab &tab) {
+    tab.n_groups = 0;
+    int r = 0;
+    while (r < tab.n_rows) {
+        int n = 1;
+        while (r + n < tab.n_rows && n < ATT_TQ && tab.row_stream[r + n] == tab.row_stream[r] &&
+               tab.row_pos[r + n] == tab.row_pos[r] + n)
+            ++n;
+        tab.grp_row0[tab.n_groups] = r;
+        tab.grp_n[tab.n_groups] = n;
+        tab.grp_pos[tab.n_groups] = tab.row_pos[r];
+        tab.grp_stream[tab.n_groups] = tab.row_stream[r];
+        ++tab.n_groups;
+        r += n;
+    }
+}
+
+static int run_forward(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits, void *stream) {
+    if (s->m->cfg.dtype == SD_BF16)
+        return forward_impl<bf16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+    return forward_impl<float>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+}
+
 extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
                                   float *logits_out, long ld_logits, void *stream) {
     SD_REQUIRE(s && tokens, "sd_session_forward: null argument");
     SD_REQUIRE(n_new >= 1 && pos0 >= 0, "sd_session_forward: n_new=%d pos0=%d", n_new, pos0);
     SD_REQUIRE(n_logits >= 0 && n_logits <= n_new, "sd_session_forward: n_logits=%d of n_new=%d", n_logits, n_new);
     SD_REQUIRE(n_logits == 0 || logits_out, "sd_session_forward: logits_out is null");
-    if (n_new > s->max_rows || n_new > 64 || pos0 + n_new > s->max_seq) {
+    if (n_new > s->max_rows || n_new > SD_MAX_ROWS || pos0 + n_new > s->max_seq) {
         sd_set_error("sd_session_forward: n_new=%d (max_rows %d, <=64), pos0+n_new=%d (max_seq %d)", n_new,
                      s->max_rows, pos0 + n_new, s->max_seq);
         return SD_ERR_CAPACITY;
     }
-    if (s->m->cfg.dtype == SD_BF16)
-        return forward_impl<bf16_t>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
-    return forward_impl<float>(s, tokens, n_new, pos0, n_logits, logits_out, ld_logits, (hipStream_t)stream);
+    RowTab tab = {};
+    tab.n_rows = n_new;
+    tab.n_streams = 1;
+    tab.n_logit_rows = n_logits;
+    tab.tok_base[0] = tokens - pos0;            // indexed by absolute position, only ever read at pos0 .. pos0+n_new-1
+    tab.kv_base[0] = s->kv;
+    tab.max_seq[0] = s->max_seq;
+    for (int i = 0; i < n_new; ++i) { tab.row_pos[i] = pos0 + i; tab.row_stream[i] = 0; }
+    for (int i = 0; i < n_logits; ++i) tab.xmap[i] = (unsigned char)(n_new - n_logits + i);
+    finish_table(tab);
+    return run_forward(s, tab, pos0 + n_new, logits_out, ld_logits, stream);
+}
+
+// Stream-batched forward: the new rows of up to 16 independent sequences go through ONE pass
+// over the weights.  Every item names its own session (KV arena), token buffer (device int32, indexed by absolute
+// position), cache length pos0, number of new rows and how many of its last rows need logits.  Activations use
+// items[0].session's scratch; all sessions must belong to the same model.  Logit rows come out packed in item order.
+extern "C" int sd_batch_forward(const sd_batch_item *items, int n_items, float *logits_out, long ld_logits,
+                                void *stream) {
+    SD_REQUIRE(items && n_items >= 1 && n_items <= SD_MAX_STREAMS, "sd_batch_forward: 1..%d items", SD_MAX_STREAMS);
+    sd_session *s0 = items[0].session;
+    SD_REQUIRE(s0, "sd_batch_forward: null session");
+    RowTab tab = {};
+    int rows = 0, nlog = 0, s_max = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const sd_batch_item &it = items[i];
+        SD_REQUIRE(it.session && it.seq && it.session->m == s0->m, "sd_batch_forward: item %d: null or foreign session", i);
+        SD_REQUIRE(it.n_new >= 1 && it.pos0 >= 0 && it.n_logits >= 0 && it.n_logits <= it.n_new,
+                   "sd_batch_forward: item %d: n_new=%d pos0=%d n_logits=%d", i, it.n_new, it.pos0, it.n_logits);
+        if (it.pos0 + it.n_new > it.session->max_seq || rows + it.n_new > std::min(s0->max_rows, SD_MAX_ROWS)) {
+            sd_set_error("sd_batch_forward: item %d overflows (rows %d+%d of %d, positions %d of %d)", i, rows, it.n_new,
+                         std::min(s0->max_rows, SD_MAX_ROWS), it.pos0 + it.n_new, it.session->max_seq);
+            return SD_ERR_CAPACITY;
+        }
+        tab.tok_base[i] = it.seq;
+        tab.kv_base[i] = it.session->kv;
+        tab.max_seq[i] = it.session->max_seq;
+        for (int r = 0; r < it.n_new; ++r) {
+            tab.row_pos[rows + r] = it.pos0 + r;
+            tab.row_stream[rows + r] = (unsigned char)i;
+        }
+        for (int r = 0; r < it.n_logits; ++r) tab.xmap[nlog++] = (unsigned char)(rows + it.n_new - it.n_logits + r);
+        rows += it.n_new;
+        s_max = std::max(s_max, it.pos0 + it.n_new);
+    }
+    SD_REQUIRE(nlog == 0 || logits_out, "sd_batch_forward: logits_out is null");
+    tab.n_rows = rows;
+    tab.n_streams = n_items;
+    tab.n_logit_rows = nlog;
+    finish_table(tab);
+    return run_forward(s0, tab, s_max, logits_out, ld_logits, stream);
 }
 
 // ---- standalone weight-streaming GEMM (unit tests + kernel-level roofline runs) --------------

@@ -9,6 +9,24 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
+// Row table of one forward, passed BY VALUE in the kernel arguments (no device copy to keep alive): rows may belong to
+// several independent sequences ("streams", SURVEY.md 8(e)/(f): stream-batched decode) that share the GEMMs and differ
+// in position, token source and KV arena.  A single-sequence forward is a table with one stream.
+#define SD_MAX_ROWS 64
+#define SD_MAX_STREAMS 16
+#define SD_MAX_GROUPS 32
+struct RowTab {
+    int n_rows, n_streams, n_groups, n_logit_rows;
+    int row_pos[SD_MAX_ROWS];                       // absolute position of row m in its sequence
+    unsigned char row_stream[SD_MAX_ROWS];          // stream of row m
+    unsigned char xmap[SD_MAX_ROWS];                // rows of the hidden state that feed the lm_head, in output order
+    const int32_t *tok_base[SD_MAX_STREAMS];        // stream's token buffer, indexed by absolute position
+    void *kv_base[SD_MAX_STREAMS];                  // stream's KV arena [L][2][Hkv][max_seq][D]
+    int max_seq[SD_MAX_STREAMS];                    // that arena's capacity
+    // attention groups: <= ATT_TQ consecutive rows of one stream (first row, count, position of the first row, stream)
+    int grp_row0[SD_MAX_GROUPS], grp_n[SD_MAX_GROUPS], grp_pos[SD_MAX_GROUPS], grp_stream[SD_MAX_GROUPS];
+};
+
 enum { NORM_RMS = 0, NORM_LN = 1 };
 enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual feeds the next GEMM / replaces x / no norm
 
@@ -25,10 +43,11 @@ struct GemmEpi {
     bf16_t *out;              // ACT: act[M][n_out]            QKV: q buffer [M][Hq*D]
     const bf16_t *bias;       // OPT biases (NULL for llama)
     int n_out;                // ACT: row stride of act (= inter)
-    bf16_t *karena, *varena;  // QKV: this layer's K / V arena [Hkv][max_seq][D]
     const bf16_t *cos_t, *sin_t;
-    int Hq, Hkv, D, pos0, max_seq;
+    int Hq, Hkv, D, layer;    // QKV: K / V rows go to tab.kv_base[stream] + layer offset, at position tab.row_pos[m]
     float q_scale;
+    int use_xmap;             // lm_head: activation row m is tab.xmap[m] of X
+    RowTab tab;
 };
 
 __device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, float d) {
@@ -60,7 +79,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
     for (int t = 0; t < MT; ++t) {
         const int m = t * 16 + mrow;
         mv[t] = m < M;
-        xp[t] = X + (size_t)(mv[t] ? m : 0) * K + (size_t)ks0 * 32 + kq;
+        const int msrc = mv[t] ? (e.use_xmap ? (int)e.tab.xmap[m] : m) : 0;
+        xp[t] = X + (size_t)msrc * K + (size_t)ks0 * 32 + kq;
     }
     f32x4 acc[NTW][MT];
 #pragma unroll
@@ -165,9 +185,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             const f32x4 r = folded(j, t, l);
             const int head = col / e.D, within = col - head * e.D;
             const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
+            const int strm = e.tab.row_stream[m], pos = e.tab.row_pos[m], mseq = e.tab.max_seq[strm];
+            bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
             bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
-                               : (is_k ? e.karena + ((size_t)(head - e.Hq) * e.max_seq + e.pos0 + m) * e.D
-                                       : e.varena + ((size_t)(head - e.Hq - e.Hkv) * e.max_seq + e.pos0 + m) * e.D);
+                               : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
+                                       : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
             float x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const int d = (within >> 1) + pr;
-                    const float c = to_f(e.cos_t[(size_t)(e.pos0 + m) * hd + d]), sn = to_f(e.sin_t[(size_t)(e.pos0 + m) * hd + d]);
+                    const float c = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
                     const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
                     dst[d] = (bf16_t)(rnd<bf16_t>(x0 * c) + rnd<bf16_t>(-x1 * sn));
                     dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * c) + rnd<bf16_t>(x0 * sn));
@@ -193,13 +215,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 
 // fp32 storage (parity runs on small models): one wave per output column, lanes stride K.
 __global__ __launch_bounds__(256) void gemm_f32_simple(const float *__restrict__ W, const float *__restrict__ X,
-                                                      float *__restrict__ part, int M, int N, int K) {
+                                                      float *__restrict__ part, int M, int N, int K, RowTab tab,
+                                                      int use_xmap) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const float *w = W + (size_t)n * K;
     for (int m = 0; m < M; ++m) {
-        const float *x = X + (size_t)m * K;
+        const float *x = X + (size_t)(use_xmap ? (int)tab.xmap[m] : m) * K;
         float a = 0.f;
         for (int k = lane; k < K; k += 64) a = fmaf(w[k], x[k], a);
         a = wave_sum(a);
@@ -275,12 +298,13 @@ __device__ __forceinline__ f32x4 reduce_part4(const float *__restrict__ part, in
 // Embedding gather (+ OPT learned positions when there is no project_in)
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void embed_kernel(const int32_t *__restrict__ tokens, const T *__restrict__ table, int dim,
-                             const T *__restrict__ pos_table, int pos0, int pos_off, T *__restrict__ out) {
+__global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, const T *__restrict__ pos_table,
+                             int pos_off, T *__restrict__ out) {
     const int row = blockIdx.x;
-    const int tok = tokens[row];
+    const int pos = tab.row_pos[row];
+    const int tok = tab.tok_base[tab.row_stream[row]][pos];
     const T *src = table + (size_t)tok * dim;
-    const T *ps = pos_table ? pos_table + (size_t)(pos0 + row + pos_off) * dim : nullptr;
+    const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * dim : nullptr;
     for (int i = threadIdx.x; i < dim; i += blockDim.x) {
         float v = to_f(src[i]);
         if (ps) v = rnd<T>(v + to_f(ps[i]));
@@ -291,8 +315,9 @@ __global__ void embed_kernel(const int32_t *__restrict__ tokens, const T *__rest
 // x = rnd(rnd(sum part) + pos)   (OPT project_in output plus learned positions, modeling_opt.py:669-672)
 template <typename T>
 __global__ void reduce_addpos_kernel(const float *__restrict__ part, int S, size_t stride_s, int N,
-                                     const T *__restrict__ pos_table, int pos0, int pos_off, T *__restrict__ out) {
+                                     const T *__restrict__ pos_table, RowTab tab, int pos_off, T *__restrict__ out) {
     const int row = blockIdx.x;
+    const int pos0 = tab.row_pos[row] - row;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         float v = reduce_part<T>(part, S, stride_s, (size_t)row * N + i, nullptr, i);
         if (pos_table) v = rnd<T>(v + to_f(pos_table[(size_t)(pos0 + row + pos_off) * N + i]));
@@ -392,18 +417,20 @@ template <typename T>
 __global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_t stride_s, int Nqkv,
                                     const T *__restrict__ bias, const T *__restrict__ cos_t,
                                     const T *__restrict__ sin_t, int arch, float q_scale, int Hq, int Hkv, int D,
-                                    int pos0, int max_seq, T *__restrict__ qbuf, T *__restrict__ karena,
-                                    T *__restrict__ varena) {
+                                    RowTab tab, int layer, T *__restrict__ qbuf) {
     const int row = blockIdx.x, head = blockIdx.y, d = threadIdx.x, hd = D >> 1;
     if (d >= hd) return;
+    const int strm = tab.row_stream[row], pos = tab.row_pos[row], max_seq = tab.max_seq[strm];
+    T *karena = (T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
+    T *varena = karena + (size_t)Hkv * max_seq * D;
     const int col0 = head * D + d, col1 = col0 + hd;
     const float v0 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col0, bias, col0);
     const float v1 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col1, bias, col1);
     float o0 = v0, o1 = v1;
     const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
     if (arch == SD_ARCH_LLAMA && (is_q || is_k)) {
-        const float c = to_f(cos_t[(size_t)(pos0 + row) * hd + d]);
-        const float s = to_f(sin_t[(size_t)(pos0 + row) * hd + d]);
+        const float c = to_f(cos_t[(size_t)pos * hd + d]);
+        const float s = to_f(sin_t[(size_t)pos * hd + d]);
         // q*cos + rotate_half(q)*sin with rotate_half = cat(-x2, x1)   (modeling_llama.py:173-188)
         o0 = rnd<T>(rnd<T>(v0 * c) + rnd<T>(-v1 * s));
         o1 = rnd<T>(rnd<T>(v1 * c) + rnd<T>(v0 * s));
@@ -417,7 +444,7 @@ __global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_
         q[d + hd] = from_f<T>(o1);
     } else {
         const int kvh = is_k ? head - Hq : head - Hq - Hkv;
-        T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + pos0 + row) * D;
+        T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + pos) * D;
         dst[d] = from_f<T>(o0);
         dst[d + hd] = from_f<T>(o1);
     }
@@ -445,21 +472,29 @@ __device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
 }
 #define ATT_TQ 8
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, const T *__restrict__ karena,
-                                                  const T *__restrict__ varena, T *__restrict__ out, int n_new,
-                                                  int pos0, int max_seq, int Hq, int Hkv, int arch,
+__global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
+                                                  T *__restrict__ out, int Hq, int Hkv, int arch,
                                                   float inv_sqrt_d, int s_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     float *red = qs + ATT_TQ * D;                                 // [4 waves][TQ][D]
     float *sc = red + 4 * ATT_TQ * D;                             // [TQ][s_cap]
-    const int head = blockIdx.x, r0 = blockIdx.y * ATT_TQ;
-    const int nr = min(ATT_TQ, n_new - r0);
+    // one group = up to ATT_TQ consecutive rows of one stream; "pos0 + r0" below is the position of its first row
+    const int head = blockIdx.x, r0 = tab.grp_row0[blockIdx.y];
+    const int nr = tab.grp_n[blockIdx.y];
+    const int strm = tab.grp_stream[blockIdx.y], max_seq = tab.max_seq[strm];
+    const int pos0 = tab.grp_pos[blockIdx.y] - r0;
     const int kvh = head / (Hq / Hkv);
+    const T *karena = (const T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
     const T *K = karena + (size_t)kvh * max_seq * D;
-    const T *Vv = varena + (size_t)kvh * max_seq * D;
+    const T *Vv = karena + (size_t)(Hkv + kvh) * max_seq * D;
     const int tid = threadIdx.x;
     const int s_hi = pos0 + r0 + nr;                              // keys visible to the last row of the group
+#ifdef SD_DEBUG_ATTN
+    if (tid == 0 && head == 0 && layer == 0)
+        printf("attn grp %d: r0=%d nr=%d strm=%d pos0=%d s_hi=%d max_seq=%d s_cap=%d n_groups=%d rowpos=%d,%d\n", (int)blockIdx.y, r0, nr,
+               strm, pos0, s_hi, max_seq, s_cap, tab.n_groups, tab.row_pos[0], tab.row_pos[1]);
+#endif
 
     for (int i = tid; i < ATT_TQ * D; i += 256) {
         const int t = i / D, d = i - t * D;

@@ -165,7 +165,7 @@ class SpecDecModel:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
+        if h and lib is not None:              # (module globals are gone at interpreter shutdown)
             lib.sd_model_destroy(h)
             self.handle = None
 
@@ -239,7 +239,7 @@ class Session:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
+        if h and lib is not None:
             lib.sd_session_destroy(h)
             self.handle = None
 
@@ -305,3 +305,28 @@ def as_specdec_model(model, dtype: Optional[torch.dtype] = None) -> SpecDecModel
             raise NotImplementedError("encoder-decoder models (reference speculative_sampling.py:1946,1958) are out of scope")
         _MODEL_CACHE[key] = SpecDecModel.from_hf(model, dtype=dtype)
     return _MODEL_CACHE[key]
+
+
+def batch_forward(sessions: List[Session], seqs: List[torch.Tensor], n_new: List[int], n_logits: List[int],
+                  logits_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Stream-batched forward (sd_batch_forward): stream i feeds seqs[i][cache_len : cache_len + n_new[i]] (seqs[i] is
+    that stream's whole int32 token buffer on the device, indexed by absolute position).  Returns the packed fp32 logits
+    of the last n_logits[i] rows of every stream, in stream order.  All sessions share one model."""
+    B = len(sessions)
+    items = (_lib.SdBatchItem * B)()
+    for i, (ses, sq) in enumerate(zip(sessions, seqs)):
+        assert sq.dtype == torch.int32 and sq.is_cuda
+        items[i].session = ses.handle
+        items[i].seq = sq.data_ptr()
+        items[i].pos0 = ses.cache_len
+        items[i].n_new = int(n_new[i])
+        items[i].n_logits = int(n_logits[i])
+    tot = int(sum(n_logits))
+    if logits_out is None:
+        logits_out = sessions[0].logits
+    assert tot <= logits_out.shape[0]
+    check(lib.sd_batch_forward(items, B, logits_out.data_ptr() if tot else None, logits_out.stride(0), _stream()),
+          "sd_batch_forward")
+    for ses, n in zip(sessions, n_new):
+        ses.cache_len += int(n)
+    return logits_out[:tot]

@@ -513,3 +513,33 @@ def test_get_score_matches_oracle(hip):
     lp = torch.gather(torch.log_softmax(lg, -1), -1, out[:, 1:, None])
     want = float(lp[:, 19:, :].mean())
     assert abs(got - want) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_batch_forward_equals_per_stream_forward(hip, dtype):
+    """sd_batch_forward: three sequences of different lengths share one pass over the weights; every stream's logits and
+    KV rows equal what its own sd_session_forward produces (fp32: bit-exact, the rows are independent)."""
+    from llmspeculativesampling_amd.config import ModelConfig
+    cfg = ModelConfig(**MID_CFGS["llama_d64_gqa"]) if dtype == torch.bfloat16 else load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 31, dtype=dtype)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    rng = np.random.default_rng(8)
+    lens, new, nlog = [17, 40, 9], [1, 2, 5], [1, 1, 5]
+    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(L + n,)).astype(np.int32)).cuda() for L, n in zip(lens, new)]
+    solo = [m.new_session(96) for _ in lens]
+    both = [m.new_session(96) for _ in lens]
+    want = []
+    for ses, ses2, sq, L, n, nl in zip(solo, both, seqs, lens, new, nlog):
+        ses.forward(sq[:L], 0)
+        ses2.forward(sq[:L], 0)
+        want.append(ses.forward(sq[L:L + n], nl).clone())
+    got = hip.engine.batch_forward(both, seqs, new, nlog).clone()
+    want = torch.cat(want, 0)
+    if dtype == torch.float32:
+        assert torch.equal(got, want)
+    else:
+        assert float((got - want).abs().max()) <= 0.03 * float(want.abs().max())
+    for a, b, L, n in zip(solo, both, lens, new):
+        assert a.cache_len == b.cache_len == L + n
+        ka, kb = a.past_key_values()[-1][0], b.past_key_values()[-1][0]
+        assert torch.equal(ka, kb) if dtype == torch.float32 else float((ka.float() - kb.float()).abs().max()) < 0.05
