@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-max-len", type=int, default=16)
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="wall budget for the CPU baseline runs")
     ap.add_argument("--cpu-prompt-len", type=int, default=128)
+    ap.add_argument("--batch-streams", type=int, default=1,
+                    help="throughput mode (SURVEY 8(f)): this many prompt streams decode in lockstep per step and share every "
+                         "weight pass (speculative_sampling_batch); 1 = the single-stream path of BASELINE configs[1]")
     ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
     return ap.parse_args()
 
@@ -169,7 +172,7 @@ def main():
     from llmspeculativesampling_amd.config import load_config
     from llmspeculativesampling_amd.engine import SpecDecModel
     from llmspeculativesampling_amd.noise import DeviceNoise, HostTorchNoise
-    from llmspeculativesampling_amd.sampling import speculative_sampling
+    from llmspeculativesampling_amd.sampling import speculative_sampling, speculative_sampling_batch
 
     dcfg, tcfg = load_config(args.draft), load_config(args.target)
     max_pos = args.prompt_len + args.max_len + args.gamma + 8
@@ -184,7 +187,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    BS = args.batch_streams
+
     def run_step(stream, logs=None):
+        if BS > 1:
+            prompts = [prompt_for(stream * BS + j, tcfg.vocab_size, args.prompt_len).cuda() for j in range(BS)]
+            outs, ds = speculative_sampling_batch(prompts, dm, tm, eos_token_id=2, pad_token_id=None, max_len=args.max_len,
+                                                  gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True,
+                                                  seeds=[2000 + stream * BS + j for j in range(BS)],
+                                                  _timing=logs if isinstance(logs, dict) else None)
+            d = {"acc_len": [a for x in ds for a in x["acc_len"]], "target_call_times": sum(x["target_call_times"] for x in ds)}
+            new = sum(int(o.shape[1]) - args.prompt_len for o in outs)
+            return outs, d, new
         prompt = prompt_for(stream, tcfg.vocab_size, args.prompt_len).cuda()
         if args.rng == "device":
             nz = DeviceNoise(seed=2000 + stream)
@@ -194,7 +208,7 @@ def main():
         out, d = speculative_sampling(prompt, dm, tm, eos_token_id=2, pad_token_id=None, max_len=args.max_len,
                                       gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True, rng=nz,
                                       _event_logs=logs)
-        return out, d
+        return [out], d, int(out.shape[1]) - args.prompt_len
 
     # streams: rank r takes s = r, r+world, ... (round-robin)
     for i in range(args.warmup):
@@ -205,17 +219,17 @@ def main():
     logs = {"draft_ms": [], "target": []} if args.rng == "device" else ([], [])
     outs = []
     for i in range(args.steps):
-        out, d = run_step(rank + i * world, logs)
-        new_tokens += int(out.shape[1]) - args.prompt_len
+        o_list, d, n_new_tok = run_step(rank + i * world, logs)
+        new_tokens += n_new_tok
         acc_sum += int(sum(d["acc_len"]))
         n_iters += int(d["target_call_times"])
-        outs.append(out)
+        outs.extend(o_list)
     if dist is not None:
         # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
         from llmspeculativesampling_amd.dist import gather_streams
         width = args.prompt_len + args.max_len + args.gamma + 1
-        all_streams = gather_streams(outs, args.steps * world, width, device=comm_dev)
-        assert len(all_streams) == args.steps * world
+        all_streams = gather_streams(outs, args.steps * world * BS, width, device=comm_dev)
+        assert len(all_streams) == args.steps * world * BS
     barrier()
     elapsed = time.time() - t0
     stats = torch.tensor([elapsed, float(new_tokens), float(acc_sum), float(n_iters)], dtype=torch.float64, device=comm_dev)
@@ -231,7 +245,13 @@ def main():
     # the stream every kernel was launched on).  One "launch" = one verify step = one target forward over
     # gamma+1 rows + norm_probs, a fixed chain of kernels; algorithmic bytes per SURVEY.md 8(d).
     ver_ms, ver_S, pre_ms = [], [], []
-    if isinstance(logs, dict):
+    if isinstance(logs, dict) and BS > 1:
+        for (e0, e1, nstr, ctx) in logs.get("verify", []):
+            if nstr == BS:
+                ver_ms.append(e0.elapsed_time(e1))
+                ver_S.append(ctx)
+        drf_ms = []
+    elif isinstance(logs, dict):
         for (ms, n_new, upto) in logs["target"]:
             (ver_ms if n_new == args.gamma + 1 else pre_ms).append(ms)
             if n_new == args.gamma + 1:
@@ -247,6 +267,9 @@ def main():
     t_ver = float(np.mean(ver_ms)) if ver_ms else float("nan")
     S_mean = float(np.mean(ver_S)) if ver_S else float(args.prompt_len + args.max_len / 2)
     b_ver = algorithmic_verify_bytes(tcfg, args.gamma, S_mean)
+    if BS > 1:       # one pass over the weights serves BS streams; KV and logits scale with the stream count
+        w_only = tcfg.n_params(streamed_only=True) * 2
+        b_ver = w_only * ((BS * (args.gamma + 1) + 63) // 64) + (b_ver - w_only) * BS
     achieved = b_ver / (t_ver * 1e-3) / 1e9 if ver_ms else float("nan")
     # HBM traffic per verify step from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and
     # WRITE_SIZE do not fit one pass and cannot be combined with the timed run), so the committed summary of the
@@ -255,7 +278,7 @@ def main():
     traffic = None
     try:
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-        if cands and args.target == "llama-2-13b" and args.gamma == 4:
+        if cands and args.target == "llama-2-13b" and args.gamma == 4 and BS == 1:
             traffic = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["traffic_bytes_per_verify"]
     except Exception:
         traffic = None
@@ -270,7 +293,7 @@ def main():
     }
 
     # ---- per-op-class split of one verify step (events around every launch; outside the timed region)
-    if args.profile_classes and rank == 0:
+    if args.profile_classes and rank == 0 and BS == 1:
         ses = tm.new_session(max_pos)
         toks = prompt_for(0, tcfg.vocab_size, args.prompt_len + args.gamma + 1).cuda()[0].to(torch.int32)
         done = 0
@@ -304,9 +327,10 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt {args.prompt_len}, "
-                               f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, 1 stream per step per GPU, "
+                               f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, {BS} stream(s) per step per GPU"
+                               f"{' decoded in lockstep through shared weight passes' if BS > 1 else ''}, "
                                f"rng={args.rng}; random-init weights (accept-len ~0 by construction)",
-                   "streams": args.steps * world, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+                   "streams": args.steps * world * BS, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "mean_accept_len": acc_sum / max(1.0, n_iters), "iterations": n_iters, "new_tokens": new_tokens,
         "roofline": roofline, "model_build_s": t_build,
     }

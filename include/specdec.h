@@ -67,6 +67,19 @@ int sd_norm_sample(const float *logits, int V, float temperature, int top_k, flo
                    uint64_t philox_seed, uint64_t draw_index, int *tok_out, int *sample_err, void *workspace,
                    void *stream);
 
+/* Batched form of sd_norm_probs / sd_norm_sample for stream-batched decode: row r of `logits` is normalised into
+ * rows[r].probs_out (rows of different streams live in different arenas); with sample != 0 each row also draws its
+ * token into rows[r].tok_out from its own exp_noise row or Philox (seed, draw).  `rows` is a host array. */
+typedef struct {
+    float *probs_out;
+    int *err;                 /* device int or NULL */
+    const float *exp_noise;   /* device row or NULL (Philox) */
+    uint64_t philox_seed, draw_index;
+    int *tok_out, *sample_err;
+} sd_norm_row;
+int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                  int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace, void *stream);
+
 /* sample (utils.py:213-233) for num_samples == 1: argmax_i probs[i] / noise[i] (first index wins
  * ties), then the "< 1e-9 -> argmax(probs)" fix-up.  exp_noise is a device row of Exp(1) variates
  * in the reference's draw order (parity mode), or NULL to draw them on the device from Philox
@@ -89,6 +102,7 @@ typedef struct {
                               bit1 'prob error'; bit2 all gamma accepted; bit3 an error word of the iteration was set */
     float p_at[16];        /* target prob of each drafted token (for the acc_rate statistic, :1966-1971)      */
     float q_at[16];        /* draft prob of each drafted token                                                */
+    int32_t drafted[16];   /* the gamma drafted token ids seq[L .. L+gamma) (saves a second device->host copy)      */
 } sd_accept_result;
 
 /* Accept scan (speculative_sampling.py:1964-1991): for i < gamma, j = seq[L+i]; reject iff
@@ -108,6 +122,22 @@ int sd_accept_scan(const float *p_hist, const float *q_hist, long ld, const int3
 int sd_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L,
                 int gamma, const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
                 sd_accept_result *res, int32_t *seq_len, void *stream);
+
+/* sd_accept_scan + sd_resample for up to 16 independent streams in two launches (stream-batched decode).
+ * Per item: its probability arenas, token buffer, prefix length L, the gamma uniforms r (or NULL: Philox
+ * (philox_seed, draw_scan + i)), the resample noise row (or NULL: Philox (philox_seed, draw_resample)), the
+ * device result block, and optionally n_err device error words folded into res.flags bit3. `items` is a host array. */
+typedef struct {
+    const float *p_hist, *q_hist;
+    int32_t *seq;
+    int32_t L;
+    const float *r, *exp_noise;
+    uint64_t philox_seed, draw_scan, draw_resample;
+    sd_accept_result *res;
+    const int *err_flags;
+    int32_t n_err;
+} sd_accept_item;
+int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder model + KV arena           reference sampling/models/modeling_{llama,opt}.py,

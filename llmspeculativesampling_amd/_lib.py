@@ -21,7 +21,18 @@ PROFILE_CLASS_NAMES = ["gemm", "attention", "norm_residual", "qkv_rope_append", 
 
 class SdAcceptResult(C.Structure):
     _fields_ = [("n_accepted", C.c_int32), ("n", C.c_int32), ("next_token", C.c_int32), ("flags", C.c_int32),
-                ("p_at", C.c_float * 16), ("q_at", C.c_float * 16)]
+                ("p_at", C.c_float * 16), ("q_at", C.c_float * 16), ("drafted", C.c_int32 * 16)]
+
+
+class SdNormRow(C.Structure):
+    _fields_ = [("probs_out", C.c_void_p), ("err", C.c_void_p), ("exp_noise", C.c_void_p), ("philox_seed", C.c_uint64),
+                ("draw_index", C.c_uint64), ("tok_out", C.c_void_p), ("sample_err", C.c_void_p)]
+
+
+class SdAcceptItem(C.Structure):
+    _fields_ = [("p_hist", C.c_void_p), ("q_hist", C.c_void_p), ("seq", C.c_void_p), ("L", C.c_int32),
+                ("r", C.c_void_p), ("exp_noise", C.c_void_p), ("philox_seed", C.c_uint64), ("draw_scan", C.c_uint64),
+                ("draw_resample", C.c_uint64), ("res", C.c_void_p), ("err_flags", C.c_void_p), ("n_err", C.c_int32)]
 
 
 class SdBatchItem(C.Structure):
@@ -57,6 +68,8 @@ SYMBOLS = [
     ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP, _VP]),
     ("sd_norm_workspace_bytes", C.c_size_t, [_I]),
     ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
+    ("sd_norm_batch", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, C.POINTER(SdNormRow), _I, _VP, _VP]),
+    ("sd_accept_batch", _I, [C.POINTER(SdAcceptItem), _I, _L, _I, _I, _VP]),
     ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),

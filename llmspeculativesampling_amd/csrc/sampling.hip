@@ -164,6 +164,18 @@ __device__ __forceinline__ void rank_sort(NormShared &S, int n) {
 // part of the output row and keeps the few elements above a local threshold that is guaranteed to lie at or below
 // the chunk's k-th largest value (so every element >= the row's k-th largest survives).  norm_probs_kernel then
 // works on <= 1024 candidates and scatters the <= k non-zero probabilities.
+// Per-row destinations of a batched launch (rows of different streams go to different arenas / token buffers),
+// passed by value; at most SD_NORM_BATCH rows per launch.
+#define SD_NORM_BATCH 16
+struct NormTab {
+    float *out[SD_NORM_BATCH];
+    int *err[SD_NORM_BATCH];
+    int *tok_out[SD_NORM_BATCH];
+    int *samp_err[SD_NORM_BATCH];
+    const float *noise[SD_NORM_BATCH];
+    uint64_t seed[SD_NORM_BATCH], draw[SD_NORM_BATCH];
+};
+
 #define NB_SPLIT 16
 #define CAND_CAP 192
 #define CAND_MAXIT 4
@@ -172,7 +184,8 @@ struct CandRow { CandHdr hdr[NB_SPLIT]; uint2 cand[NB_SPLIT][CAND_CAP]; };
 
 __global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict__ logits, long ld_in, int V,
                                                        float temperature, int top_k, int bf16_round,
-                                                       float *__restrict__ out, long ld_out, CandRow *__restrict__ ws) {
+                                                       float *__restrict__ out, long ld_out, CandRow *__restrict__ ws,
+                                                       NormTab tab, int use_tab) {
     __shared__ uint32_t wk_sh[4];
     __shared__ uint32_t mk_sh[256];
     __shared__ int cnt_sh;
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict_
     __shared__ int redi[16];
     const int row = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float4 *x4 = reinterpret_cast<const float4 *>(logits + (size_t)row * ld_in);
-    float4 *o4 = reinterpret_cast<float4 *>(out + (size_t)row * ld_out);
+    float4 *o4 = reinterpret_cast<float4 *>(use_tab ? tab.out[blockIdx.y] : out + (size_t)row * ld_out);
     const int V4 = V >> 2, C4 = (V4 + NB_SPLIT - 1) / NB_SPLIT;
     const int lo = b * C4, hi = min(V4, lo + C4);
     float4 z[CAND_MAXIT];
@@ -257,13 +270,22 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                                                        int staged, float *__restrict__ out, long ld_out,
                                                        int *__restrict__ err, const float *__restrict__ noise,
                                                        uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
-                                                       int *__restrict__ samp_err, const CandRow *__restrict__ ws) {
+                                                       int *__restrict__ samp_err, const CandRow *__restrict__ ws,
+                                                       NormTab tab, int use_tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NormShared &S = *reinterpret_cast<NormShared *>(smem);
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *x = logits + (size_t)row * ld_in;
-    float *o = out + (size_t)row * ld_out;
+    float *o = use_tab ? tab.out[blockIdx.x] : out + (size_t)row * ld_out;
+    int *errp = use_tab ? tab.err[blockIdx.x] : (err ? err + row : nullptr);
+    if (use_tab) {                                                // batched launch: per-row sampling parameters
+        noise = tab.noise[blockIdx.x];
+        seed = tab.seed[blockIdx.x];
+        draw = tab.draw[blockIdx.x];
+        tok_out = tab.tok_out[blockIdx.x];
+        samp_err = tab.samp_err[blockIdx.x];
+    }
     const uint32_t neg_inf_key = 0x007fffffu;                     // fkey(-inf)
 
     auto load_z = [&](int i) -> float {
@@ -394,7 +416,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     if (bad || m == INFINITY || m == -INFINITY) {                 // exp(log_softmax) would hold NaN (utils.py:203)
         for (int i = tid; i < V; i += NT) o[i] = __uint_as_float(0x7fc00000u);
         if (tid == 0) {
-            if (err) err[row] = 1;
+            if (errp) *errp = 1;
             if (SAMPLE && samp_err) *samp_err = 1;
         }
         return;
@@ -662,7 +684,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
     }
     STAMP(6);
-    if (tid == 0 && err) err[row] = 0;
+    if (tid == 0 && errp) *errp = 0;
     (void)n_list;
 }
 
@@ -733,16 +755,16 @@ __global__ __launch_bounds__(NT) void max_fn_kernel(const float *__restrict__ p,
 // ---------------------------------------------------------------------------------------------
 // accept scan + resample
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void accept_scan_kernel(const float *__restrict__ p_hist,
-                                                        const float *__restrict__ q_hist, long ld,
-                                                        const int32_t *__restrict__ seq, int L, int gamma,
-                                                        const float *__restrict__ r, uint64_t seed, uint64_t draw,
-                                                        sd_accept_result *__restrict__ out) {
+__device__ __forceinline__ void accept_scan_body(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
+                                                 long ld, const int32_t *__restrict__ seq, int L, int gamma,
+                                                 const float *__restrict__ r, uint64_t seed, uint64_t draw,
+                                                 sd_accept_result *__restrict__ out) {
     const int i = threadIdx.x;
     bool reject = false;
     float p = 0.f, q = 1.f;
+    int j = -1;
     if (i < gamma) {
-        const int j = seq[L + i];
+        j = seq[L + i];
         p = p_hist[(size_t)(L + i - 1) * ld + j];
         q = q_hist[(size_t)(L + i - 1) * ld + j];
         const float ratio = (float)((double)p / (double)q);       // python double ratio, fp32 compare (:1981)
@@ -754,6 +776,7 @@ __global__ __launch_bounds__(64) void accept_scan_kernel(const float *__restrict
     if (i < 16) {
         out->p_at[i] = i < gamma ? p : 0.f;
         out->q_at[i] = i < gamma ? q : 0.f;
+        out->drafted[i] = j;
     }
     if (i == 0) {
         out->n_accepted = first;
@@ -763,13 +786,36 @@ __global__ __launch_bounds__(64) void accept_scan_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ p_hist,
-                                                     const float *__restrict__ q_hist, long ld, int V,
-                                                     int32_t *__restrict__ seq, int gamma,
-                                                     const float *__restrict__ noise, uint64_t seed, uint64_t draw,
-                                                     sd_accept_result *__restrict__ res,
-                                                     int32_t *__restrict__ seq_len,
-                                                     const int *__restrict__ err_flags, int n_err) {
+__global__ __launch_bounds__(64) void accept_scan_kernel(const float *__restrict__ p_hist,
+                                                        const float *__restrict__ q_hist, long ld,
+                                                        const int32_t *__restrict__ seq, int L, int gamma,
+                                                        const float *__restrict__ r, uint64_t seed, uint64_t draw,
+                                                        sd_accept_result *__restrict__ out) {
+    accept_scan_body(p_hist, q_hist, ld, seq, L, gamma, r, seed, draw, out);
+}
+
+// Batched form: one workgroup per stream, per-stream arguments passed by value.
+#define SD_ACCEPT_BATCH 16
+struct AcceptTab {
+    const float *p_hist[SD_ACCEPT_BATCH], *q_hist[SD_ACCEPT_BATCH];
+    int32_t *seq[SD_ACCEPT_BATCH];
+    const float *r[SD_ACCEPT_BATCH], *noise[SD_ACCEPT_BATCH];
+    sd_accept_result *res[SD_ACCEPT_BATCH];
+    const int *err_flags[SD_ACCEPT_BATCH];
+    uint64_t seed[SD_ACCEPT_BATCH], draw_scan[SD_ACCEPT_BATCH], draw_res[SD_ACCEPT_BATCH];
+    int L[SD_ACCEPT_BATCH], n_err[SD_ACCEPT_BATCH];
+};
+
+__global__ __launch_bounds__(64) void accept_scan_batch_kernel(AcceptTab t, long ld, int gamma) {
+    const int b = blockIdx.x;
+    accept_scan_body(t.p_hist[b], t.q_hist[b], ld, t.seq[b], t.L[b], gamma, t.r[b], t.seed[b], t.draw_scan[b], t.res[b]);
+}
+
+__device__ __forceinline__ void resample_body(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
+                                              long ld, int V, int32_t *__restrict__ seq, int gamma,
+                                              const float *__restrict__ noise, uint64_t seed, uint64_t draw,
+                                              sd_accept_result *__restrict__ res, int32_t *__restrict__ seq_len,
+                                              const int *__restrict__ err_flags, int n_err) {
     __shared__ SampleShared S;
     __shared__ float red[16];
     const int n = res->n;
@@ -809,13 +855,32 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
     }
 }
 
+__global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ p_hist,
+                                                     const float *__restrict__ q_hist, long ld, int V,
+                                                     int32_t *__restrict__ seq, int gamma,
+                                                     const float *__restrict__ noise, uint64_t seed, uint64_t draw,
+                                                     sd_accept_result *__restrict__ res,
+                                                     int32_t *__restrict__ seq_len,
+                                                     const int *__restrict__ err_flags, int n_err) {
+    resample_body(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, seq_len, err_flags, n_err);
+}
+
+__global__ __launch_bounds__(NT) void resample_batch_kernel(AcceptTab t, long ld, int V, int gamma) {
+    const int b = blockIdx.x;
+    resample_body(t.p_hist[b], t.q_hist[b], ld, V, t.seq[b], gamma, t.noise[b], t.seed[b], t.draw_res[b], t.res[b],
+                  (int32_t *)nullptr, t.err_flags[b], t.n_err[b]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
                        const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
-                       void *stream) {
+                       void *stream, const NormTab *tabp = nullptr) {
+    NormTab tab = {};
+    const int use_tab = tabp != nullptr;
+    if (tabp) tab = *tabp;
     const int staged = V <= LDS_ROW_LIMIT;
     const size_t base = (sizeof(NormShared) + 15) & ~size_t(15);
     const size_t lds = base + (staged ? (size_t)V * sizeof(float) : 0);
@@ -831,21 +896,21 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
     CandRow *ws = nullptr;
     if (workspace && top_k >= 1 && top_k <= 64 && V >= 4096 && (V & 3) == 0 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
         ((V >> 2) + NB_SPLIT - 1) / NB_SPLIT <= 256 * CAND_MAXIT && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(probs_out) & 15) == 0) {
+        (use_tab || (reinterpret_cast<uintptr_t>(probs_out) & 15) == 0)) {
         ws = static_cast<CandRow *>(workspace);
         hipLaunchKernelGGL(norm_cand_kernel, dim3(NB_SPLIT, rows), dim3(256), 0, (hipStream_t)stream, logits, ld_in, V,
-                           temperature, top_k, bf16_round_logits, probs_out, ld_out, ws);
+                           temperature, top_k, bf16_round_logits, probs_out, ld_out, ws, tab, use_tab);
         SD_LAUNCH_CHECK();
     }
     if (do_sample)
         hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
-                           seed, draw, tok_out, samp_err, (const CandRow *)ws);
+                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab);
     else
         hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
                            (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
-                           (const CandRow *)ws);
+                           (const CandRow *)ws, tab, use_tab);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -870,6 +935,33 @@ extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int
     SD_REQUIRE(temperature != 0.0f, "sd_norm_sample: temperature must be non-zero");
     return launch_norm(logits, 1, V, V, temperature, top_k, top_p, bf16_round_logits, probs_out, V, err_flag, true,
                        exp_noise, philox_seed, draw_index, tok_out, sample_err, workspace, stream);
+}
+
+// Batched rows: row r of `logits` (stride ld_in) is normalised into rows[r].probs_out; with `sample` each row also
+// draws its token (rows[r].tok_out) from its own noise / Philox stream.  Launches of at most SD_NORM_BATCH rows.
+extern "C" int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k,
+                             float top_p, int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace,
+                             void *stream) {
+    SD_REQUIRE(logits && rows && n_rows >= 0 && V > 0, "sd_norm_batch: bad arguments");
+    SD_REQUIRE(temperature != 0.0f, "sd_norm_batch: temperature must be non-zero");
+    for (int r0 = 0; r0 < n_rows; r0 += SD_NORM_BATCH) {
+        const int n = n_rows - r0 < SD_NORM_BATCH ? n_rows - r0 : SD_NORM_BATCH;
+        NormTab tab = {};
+        bool aligned = true;
+        for (int i = 0; i < n; ++i) {
+            const sd_norm_row &d = rows[r0 + i];
+            SD_REQUIRE(d.probs_out && (!sample || d.tok_out), "sd_norm_batch: row %d: null output", r0 + i);
+            tab.out[i] = d.probs_out; tab.err[i] = d.err; tab.tok_out[i] = d.tok_out; tab.samp_err[i] = d.sample_err;
+            tab.noise[i] = d.exp_noise; tab.seed[i] = d.philox_seed; tab.draw[i] = d.draw_index;
+            aligned = aligned && (reinterpret_cast<uintptr_t>(d.probs_out) & 15) == 0;
+        }
+        char *ws = workspace ? static_cast<char *>(workspace) + (size_t)r0 * sizeof(CandRow) : nullptr;
+        const int rc = launch_norm(logits + (size_t)r0 * ld_in, n, V, ld_in, temperature, top_k, top_p, bf16_round_logits,
+                                   tab.out[0], 4, nullptr, sample != 0, nullptr, 0, 0, nullptr, nullptr,
+                                   aligned ? ws : nullptr, stream, &tab);
+        if (rc != SD_OK) return rc;
+    }
+    return SD_OK;
 }
 
 extern "C" int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,
@@ -916,6 +1008,25 @@ int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, i
                             int n_err, hipStream_t st) {
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, gamma,
                        (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// Accept scan + residual / bonus sample for up to 16 independent streams in two launches (stream-batched decode).
+extern "C" int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, void *stream) {
+    SD_REQUIRE(items && n_items >= 1 && n_items <= SD_ACCEPT_BATCH, "sd_accept_batch: 1..%d items", SD_ACCEPT_BATCH);
+    SD_REQUIRE(gamma >= 1 && gamma <= 16 && V > 0, "sd_accept_batch: bad gamma / V");
+    AcceptTab t = {};
+    for (int i = 0; i < n_items; ++i) {
+        const sd_accept_item &it = items[i];
+        SD_REQUIRE(it.p_hist && it.q_hist && it.seq && it.res && it.L >= 1, "sd_accept_batch: item %d: bad arguments", i);
+        t.p_hist[i] = it.p_hist; t.q_hist[i] = it.q_hist; t.seq[i] = it.seq; t.r[i] = it.r; t.noise[i] = it.exp_noise;
+        t.res[i] = it.res; t.err_flags[i] = it.err_flags; t.n_err[i] = it.err_flags ? it.n_err : 0;
+        t.seed[i] = it.philox_seed; t.draw_scan[i] = it.draw_scan; t.draw_res[i] = it.draw_resample; t.L[i] = it.L;
+    }
+    hipLaunchKernelGGL(accept_scan_batch_kernel, dim3(n_items), dim3(64), 0, (hipStream_t)stream, t, ld, gamma);
+    SD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(resample_batch_kernel, dim3(n_items), dim3(NT), 0, (hipStream_t)stream, t, ld, V, gamma);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }

@@ -4,7 +4,7 @@ Same signature, return values, ``details`` keys, RNG draw order, EOS rule and ex
 loop body differs in mechanism only: tokens, both KV caches and both probability histories stay
 on the device; each iteration is gamma x (draft forward, norm_probs, sample), one target forward
 over gamma+1 rows, norm_probs, then one accept-scan + resample launch pair and a single
-device->host read of the 144-byte result block.
+device->host read of the 208-byte result block.
 """
 from __future__ import annotations
 
@@ -189,7 +189,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                         top_k, top_p, random_seed, details, noise, res_dev, res_host, tok_host, timing_log):
     """Device-RNG mode: every iteration is ONE call into libspecdec (sd_spec_iteration) that enqueues the gamma draft
     steps, the target forward, the accept scan and the resample; the host waits on the stream once per iteration and
-    reads 144 + 4*(gamma+2) bytes from pinned memory.  Same loop semantics as the Python-orchestrated path above
+    reads 208 + 4*(gamma+2) bytes from pinned memory.  Same loop semantics as the Python-orchestrated path above
     (reference speculative_sampling.py:1934-2046)."""
     dev = target._model.device
     V = target._model.cfg.vocab_size

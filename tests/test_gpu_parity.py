@@ -543,3 +543,34 @@ def test_batch_forward_equals_per_stream_forward(hip, dtype):
         assert a.cache_len == b.cache_len == L + n
         ka, kb = a.past_key_values()[-1][0], b.past_key_values()[-1][0]
         assert torch.equal(ka, kb) if dtype == torch.float32 else float((ka.float() - kb.float()).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("kw", [dict(top_k=20, top_p=0.9), dict(top_k=20, top_p=0.9, random_seed=42), dict(top_k=5, top_p=0.0, gamma=2)],
+                         ids=["plain", "seeded", "gamma2"])
+def test_stream_batched_decode_equals_per_stream(hip, kw):
+    """speculative_sampling_batch: 5 streams of different prompt lengths decode in lockstep through shared weight passes;
+    every stream's tokens / accepted lengths equal its own single-stream speculative_sampling run with the same Philox
+    seed (fp32: the rows of a pass are computed independently, so this is bit-exact), incl. a stream that stops early
+    at EOS while the others go on."""
+    from llmspeculativesampling_amd.synth import perturb_state_dict
+    cfg = load_config("tiny-llama-target")
+    dsd = make_state_dict(cfg, 11)
+    tsd = perturb_state_dict(dsd, 12, 0.12)
+    dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.float32)
+    tm = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.float32)
+    rng = np.random.default_rng(21)
+    prompts = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(1, L))).cuda() for L in (9, 30, 70, 2, 17)]
+    seeds = [900 + i for i in range(len(prompts))]
+    # choose an EOS id that stream 1 is known to generate early (from its own single-stream run)
+    probe = hip.S.speculative_sampling(prompts[1], dm, tm, -1, None, 24, rng=hip.noise.DeviceNoise(seeds[1]), **kw)
+    eos = int(probe[0, prompts[1].shape[1] + 3])
+    singles = [hip.S.speculative_sampling(p, dm, tm, eos, None, 24, details=True, rng=hip.noise.DeviceNoise(sd), **kw)
+               for p, sd in zip(prompts, seeds)]
+    outs, ds = hip.S.speculative_sampling_batch(prompts, dm, tm, eos, None, 24, details=True, seeds=seeds, **kw)
+    lens = set()
+    for (so, sdet), bo, bd in zip(singles, outs, ds):
+        assert torch.equal(so, bo), (so, bo)
+        assert sdet["acc_len"] == bd["acc_len"]
+        assert abs(float(sdet["acc_rate"]) - float(bd["acc_rate"])) < 1e-9
+        lens.add(bo.shape[1])
+    assert singles[1][0].shape[1] < prompts[1].shape[1] + 24          # the EOS stream really stopped early
