@@ -23,7 +23,8 @@ from .kvcache_model import KVCacheModel
 
 class _Stream:
     __slots__ = ("idx", "draft", "target", "seq32", "host", "noise", "ori_eos", "T", "done", "out", "acc_len",
-                 "acc_rate", "calls", "draft_len", "target_len", "err", "prompt_len")
+                 "acc_rate", "calls", "draft_len", "target_len", "err", "prompt_len", "q_ptr", "p_ptr", "seq_ptr",
+                 "err_ptr")
 
 
 @torch.no_grad()
@@ -77,12 +78,16 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
             st.draft._session.forward(st.seq32[:L - 1], 0)
             st.target._session.forward(st.seq32[:L - 1], 0)
         st.draft_len = st.target_len = L - 1
+        st.q_ptr, st.p_ptr = st.draft._probs.data_ptr(), st.target._probs.data_ptr()
+        st.seq_ptr, st.err_ptr = st.seq32.data_ptr(), st.err.data_ptr()
         streams.append(st)
 
     d_sessions = lambda ss: [s.draft._session for s in ss]
     t_sessions = lambda ss: [s.target._session for s in ss]
     norm_ws = torch.empty(lib.sd_norm_workspace_bytes(MAX_ROWS_PER_FORWARD), dtype=torch.uint8, device=dev)
     cu = _stream()
+    res_base = res_dev.data_ptr()
+    ld_bytes = streams[0].draft._probs.stride(0) * 4
     max_verify = max(1, MAX_ROWS_PER_FORWARD // (gamma + 1))     # streams per target pass
 
     while True:
@@ -103,13 +108,14 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
             logits = batch_forward(d_sessions(act), [s.seq32 for s in act], n_new, [1] * n)
             rows = (SdNormRow * n)()
             for j, (s, L) in enumerate(zip(act, Ls)):
-                rows[j].probs_out = s.draft._probs[L + i - 1].data_ptr()
-                rows[j].err = s.err[i].data_ptr()
+                # raw pointer arithmetic (one tensor view per row costs more host time than the kernels it feeds)
+                rows[j].probs_out = s.q_ptr + (L + i - 1) * ld_bytes
+                rows[j].err = s.err_ptr + 4 * i
                 rows[j].exp_noise = None
                 rows[j].philox_seed = s.noise.seed
                 rows[j].draw_index = base_draw[j] + i
-                rows[j].tok_out = s.seq32[L + i].data_ptr()
-                rows[j].sample_err = s.err[gamma + i].data_ptr()
+                rows[j].tok_out = s.seq_ptr + 4 * (L + i)
+                rows[j].sample_err = s.err_ptr + 4 * (gamma + i)
                 s.draft_len = L + i
             check(lib.sd_norm_batch(logits.data_ptr(), n, V, logits.stride(0), float(temperature), int(top_k or 0),
                                     float(top_p or 0.0), 0, rows, 1, norm_ws.data_ptr(), cu), "sd_norm_batch")
@@ -129,8 +135,8 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
             for s, L, nn in zip(grp, gL, n_new):
                 for r in range(nn):
                     pos = L + gamma - nn + r
-                    rows[k].probs_out = s.target._probs[pos].data_ptr()
-                    rows[k].err = s.err[2 * gamma + min(r, gamma)].data_ptr()
+                    rows[k].probs_out = s.p_ptr + pos * ld_bytes
+                    rows[k].err = s.err_ptr + 4 * (2 * gamma + min(r, gamma))
                     k += 1
             check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(temperature), int(top_k or 0),
                                     float(top_p or 0.0), 0, rows, 0, norm_ws.data_ptr(), cu), "sd_norm_batch")
@@ -149,17 +155,17 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
             else:
                 d_scan = s.noise.next_draws(gamma)
             it = items[j]
-            it.p_hist = s.target._probs.data_ptr()
-            it.q_hist = s.draft._probs.data_ptr()
-            it.seq = s.seq32.data_ptr()
+            it.p_hist = s.p_ptr
+            it.q_hist = s.q_ptr
+            it.seq = s.seq_ptr
             it.L = L
             it.r = r_const.data_ptr() if r_const is not None else None
             it.exp_noise = None
             it.philox_seed = s.noise.seed
             it.draw_scan = d_scan
             it.draw_resample = s.noise.next_draws(1)
-            it.res = res_dev[s.idx].data_ptr()
-            it.err_flags = s.err.data_ptr()
+            it.res = res_base + s.idx * res_sz
+            it.err_flags = s.err_ptr
             it.n_err = n_err
         check(lib.sd_accept_batch(items, n, act[0].draft._probs.stride(0), V, gamma, cu), "sd_accept_batch")
         res_host.copy_(res_dev, non_blocking=True)

@@ -574,3 +574,29 @@ def test_stream_batched_decode_equals_per_stream(hip, kw):
         assert abs(float(sdet["acc_rate"]) - float(bd["acc_rate"])) < 1e-9
         lens.add(bo.shape[1])
     assert singles[1][0].shape[1] < prompts[1].shape[1] + 24          # the EOS stream really stopped early
+
+
+def test_config1_full_size_opt_pair_fp32_vs_oracle(hip):
+    """BASELINE configs[0] at full size: opt-125m draft -> opt-350m target (post-LN, 512<->1024 projections, V=50272),
+    fp32, gamma=4, top_k 20, top_p 0.9, a 128-token prompt (SURVEY.md 8(d) C1 inputs; max_len shortened to bound the
+    CPU time of the oracle).  Same random-init weights, the oracle's recorded noise replayed into the HIP path: identical
+    token ids and accepted lengths, fp32 logits of the prefill within 1e-3."""
+    dcfg, tcfg = load_config("opt-125m"), load_config("opt-350m")
+    dsd, tsd = make_state_dict(dcfg, 0), make_state_dict(tcfg, 1)
+    g = torch.Generator().manual_seed(3)
+    prompt = torch.randint(4, tcfg.vocab_size, (1, 128), generator=g)
+    od, ot = oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd)
+    rec = oracle.RecordingNoise()
+    torch.manual_seed(123)
+    want, wd = oracle.speculative_sampling(prompt, od, ot, 2, None, 12, gamma=4, top_k=20, top_p=0.9, details=True, noise=rec)
+    dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+    tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.float32)
+    # logits of the target prefill against the oracle forward
+    ses = tm.new_session(160)
+    got_logits = ses.forward(prompt[0].to(torch.int32).cuda(), 4).cpu()
+    ref_logits = ot(prompt).logits[0, -4:].float()
+    assert float((got_logits - ref_logits).abs().max()) <= 1e-3
+    got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, 2, None, 12, gamma=4, top_k=20, top_p=0.9, details=True,
+                                         rng=hip.noise.ReplayNoise(rec.events, "cuda"))
+    assert torch.equal(got.cpu(), want)
+    assert gd["acc_len"] == wd["acc_len"]
