@@ -104,7 +104,15 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // ---- split-K policy.  A workgroup (4 waves) owns one n-tile x one k-slab and folds its waves in LDS, so
 // SB slabs reach HBM.  SB is chosen so that about `target` workgroups exist (>= 4 per CU), with at least
 // 8 k-steps (8 KiB of weights) per workgroup.
-static int gemm_ntw(int N, int M) { return (M > 16 && (N / 16) % 4 == 0) ? 4 : 1; }
+static int gemm_ntw(int N, int M) {
+    if (M <= 16) return 1;
+    const int ntl = N / 16;
+    const char *env = getenv("SD_GEMM_NTW");
+    const int want = env ? atoi(env) : 4;      // 8 tiles per wave measured slower (register pressure, too few workgroups)
+    if (want >= 8 && ntl % 8 == 0) return 8;
+    if (want >= 4 && ntl % 4 == 0) return 4;
+    return 1;
+}
 
 static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
     const int NTL = N / 16 / gemm_ntw(N, M), KS = K / 32;
@@ -291,7 +299,8 @@ template <int MT, int EPI, int NTW>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
                              int ks_per, const GemmEpi &e, hipStream_t st) {
     const int blocks = (N / 16 / NTW) * S;
-    hipLaunchKernelGGL((gemm_bf16_stream<MT, (MT > 2 ? 2 : (NTW > 1 ? 4 : 8)), EPI, NTW>), dim3(blocks), dim3(256), 0, st,
+    constexpr int UNROLL = NTW >= 8 ? 1 : (MT > 2 ? 2 : 4);        // 4 measured best for decode rows (tools/gemm_bench.py)
+    hipLaunchKernelGGL((gemm_bf16_stream<MT, UNROLL, EPI, NTW>), dim3(blocks), dim3(256), 0, st,
                        (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per, e);
 }
 
@@ -299,11 +308,31 @@ template <int EPI>
 static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
                               int ksp, const GemmEpi &e, hipStream_t st) {
     const int MT = Mpad / 16;
-    const bool wide = gemm_ntw(N, M) == 4;       // prefill rows: 4 n-tiles per workgroup reuse every activation fragment
-    if (MT == 1) launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-    else if (MT == 2) { if (wide) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    // rows beyond one m-tile (prefill, stream-batched verify): every activation fragment a wave loads is reused for
+    // NTW weight tiles, because activations and weights share the CU's load path (X:W bytes = 16*MT : 16*NTW)
+    const int ntw = gemm_ntw(N, M);
+    if (MT == 1) {
+        static const int variant = getenv("SD_GEMM_VARIANT") ? atoi(getenv("SD_GEMM_VARIANT")) : 0;   // tuning knob (tools/gemm_bench.py)
+        const int blocks = (N / 16) * S;
+        if (variant == 1)
+            hipLaunchKernelGGL((gemm_bf16_stream<1, 2, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
+                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
+        else if (variant == 2)
+            hipLaunchKernelGGL((gemm_bf16_stream<1, 8, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
+                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
+        else if (variant == 3)
+            hipLaunchKernelGGL((gemm_bf16_stream<1, 3, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
+                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
+        else
+            launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    }
+    else if (MT == 2) { if (ntw >= 4) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<2, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
-    else if (MT <= 4) { if (wide) launch_gemm_bf16<4, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else if (MT == 3) { if (ntw == 8) launch_gemm_bf16<3, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 4) launch_gemm_bf16<3, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<3, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
+    else if (MT == 4) { if (ntw == 8) launch_gemm_bf16<4, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 4) launch_gemm_bf16<4, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<4, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else { sd_set_error("gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
     return SD_OK;

@@ -55,14 +55,15 @@ __device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, f
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
-template <int MT, int UNROLL, int EPI, int NTW>
+template <int MT, int UNROLL, int EPI, int NTW, bool NT_LOADS = true>
 __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
                                                        float *__restrict__ part, int M, int Mpad, int N, int K,
                                                        int SB, int ks_per_blk, GemmEpi e) {
     // One workgroup = NTW consecutive 16-column n-tiles x one k-slab; its 4 waves take a quarter of the slab each
     // (every activation fragment a wave loads is reused for NTW weight tiles) and fold their accumulators through
     // LDS, so the number of partial slabs in HBM is SB, not 4*SB.  NTW = 1 for decode (M <= 16), 4 for prefill rows.
-    __shared__ f32x4 red[4][NTW][MT][64];
+    constexpr int NTH = NTW > 4 ? 4 : NTW;                        // n-tiles folded through LDS per pass
+    __shared__ f32x4 red[4][NTH][MT][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int NTG = (N >> 4) / NTW, KS = K >> 5;
     const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)u * 64);
+            for (int j = 0; j < NTW; ++j) w[u][j] = NT_LOADS ? __builtin_nontemporal_load(wp[j] + (size_t)u * 64) : wp[j][(size_t)u * 64];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -129,25 +130,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         }
     }
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+    for (int half = 0; half < NTW / NTH; ++half) {
+    if (half) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < MT; ++t) red[wv][j][t][lane] = acc[j][t];
+    for (int j = 0; j < NTH; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[wv][j][t][lane] = acc[half * NTH + j][t];
     __syncthreads();
     auto folded = [&](int j, int t, int l) -> f32x4 {
         return (red[0][j][t][l] + red[1][j][t][l]) + (red[2][j][t][l] + red[3][j][t][l]);
     };
     if constexpr (EPI == EPI_PART) {
-        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
             const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), nt = ntg * NTW + j;
+            const int m = t * 16 + (l & 15), nt = ntg * NTW + half * NTH + j;
             if (m < M)
                 *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(j, t, l);
         }
     } else if constexpr (EPI == EPI_ACT_SILU) {
         // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
-        for (int idx = threadIdx.x; idx < NTW * MT * 32; idx += 256) {
+        for (int idx = threadIdx.x; idx < NTH * MT * 32; idx += 256) {
             const int j = idx / (MT * 32), r2 = idx - j * (MT * 32), t = r2 >> 5, l = r2 & 31;
-            const int m = t * 16 + (l & 15), nt = ntg * NTW + j;
+            const int m = t * 16 + (l & 15), nt = ntg * NTW + half * NTH + j;
             if (m < M) {
                 const f32x4 g = folded(j, t, l), u = folded(j, t, l + 32);
                 float a[4];
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
-        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
             const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), col = (ntg * NTW + j) * 16 + (l >> 4) * 4;
+            const int m = t * 16 + (l & 15), col = (ntg * NTW + half * NTH + j) * 16 + (l >> 4) * 4;
             if (m < M) {
                 const f32x4 r = folded(j, t, l);
                 float a[4];
@@ -178,9 +182,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
         // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
         const int hd = e.D >> 1;
-        for (int idx = threadIdx.x; idx < NTW * MT * 64; idx += 256) {
+        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
             const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), col = (ntg * NTW + j) * 16 + (l >> 4) * 4;
+            const int m = t * 16 + (l & 15), col = (ntg * NTW + half * NTH + j) * 16 + (l >> 4) * 4;
             if (m >= M) continue;
             const f32x4 r = folded(j, t, l);
             const int head = col / e.D, within = col - head * e.D;
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
                 store4(dst + within, x[0], x[1], x[2], x[3]);
             }
         }
+    }
     }
 }
 

@@ -52,10 +52,20 @@ def bench(name, N, K, M=5, units=None, iters=30):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["qkv", "o", "gate_up", "down", "lm_head"]
+    which = [a for a in sys.argv[1:] if a != "rows"] or ([] if sys.argv[1:] == ["rows"] else ["qkv", "o", "gate_up", "down", "lm_head"])
     for n in which:
         N, K = SHAPES[n]
         for u in (None, 512, 768, 1024, 1280, 2048, 2560, 4096):
             bench(n, N, K, units=u)
-    for M in (1, 5, 16, 17, 32, 48, 64):
-        bench("gate_up", *SHAPES["gate_up"], M=M)
+    if not sys.argv[1:]:
+        for M in (1, 5, 16, 17, 32, 48, 64):
+            bench("gate_up", *SHAPES["gate_up"], M=M)
+    if sys.argv[1:] == ["rows"]:
+        for ntw in ("4", "8"):
+            os.environ["SD_GEMM_NTW"] = ntw
+            for n in ("qkv", "o", "gate_up", "down"):
+                for M in (40, 64):
+                    print("NTW", ntw, end=" ")
+                    bench(n, *SHAPES[n], M=M)
+    if sys.argv[1:] == ["variants"]:
+        pass
