@@ -63,7 +63,7 @@ extern "C" int sd_model_create(const sd_model_config *cfg, const sd_model_weight
     SD_REQUIRE(cfg->head_dim == 16 || cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128,
                "sd_model_create: head_dim %d not in {16,32,64,128}", cfg->head_dim);
     SD_REQUIRE(cfg->n_heads * cfg->head_dim == cfg->hidden, "sd_model_create: n_heads*head_dim != hidden");
-    SD_REQUIRE(cfg->hidden % 4 == 0, "sd_model_create: hidden %% 4 != 0");
+    SD_REQUIRE(cfg->hidden % 4 == 0 && cfg->hidden <= 8192, "sd_model_create: hidden must be a multiple of 4 and <= 8192");
     SD_REQUIRE(cfg->n_kv_heads > 0 && cfg->n_heads % cfg->n_kv_heads == 0, "sd_model_create: bad n_kv_heads");
     if (cfg->dtype == SD_BF16) {
         SD_REQUIRE(cfg->hidden % 32 == 0 && cfg->inter % 32 == 0 && cfg->vocab % 16 == 0 && cfg->opt_proj_dim % 32 == 0,
@@ -406,7 +406,8 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     T *x = (T *)s->x, *h = (T *)s->h, *qb = (T *)s->qbuf, *at = (T *)s->attn, *ac = (T *)s->act, *eb = (T *)s->ebuf;
     const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
     const int pos_off = 2;                                                   // OPT offset (modeling_opt.py:104)
-    const int rn_threads = (int)std::min<size_t>(1024, std::max<size_t>(64, align_up(H / 4, 64)));
+    // residual+norm keeps the row in registers: 2 groups of 4 columns per thread (H <= 8192)
+    const int rn_threads = (int)std::min<size_t>(1024, std::max<size_t>(64, align_up((H / 4 + RN_RG - 1) / RN_RG, 64)));
     GemmOut go;
     int rc;
 
@@ -476,7 +477,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             const int mode = pre ? RES_PRE : RES_POST;
             const T *nw = pre ? (const T *)m->n2w[l] : (const T *)m->n1w[l];
             const T *nb = pre ? (const T *)m->n2b[l] : (const T *)m->n1b[l];
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), norm_lds, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, s->part, go.S,
                                go.stride_s, H, (const T *)m->bo[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }
@@ -506,7 +507,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             } else {
                 mode = RES_POST; nw = (const T *)m->n2w[l]; nb = (const T *)m->n2b[l];
             }
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), norm_lds, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, s->part, go.S,
                                go.stride_s, H, (const T *)m->bfc2[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }

@@ -385,32 +385,95 @@ __global__ __launch_bounds__(256) void norm_kernel(const T *__restrict__ x, int 
 
 // x' = rnd(x + rnd(sum part + bias)); then per mode: PRE: x <- x', h <- norm(x');  POST: x,h <- LN(x');
 // NONE: x,h <- x'.   (residual adds: modeling_llama.py:440,446; modeling_opt.py:342-347, 363-368)
+template <typename T> __device__ __forceinline__ void load4(const T *p, float (&o)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float *p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t *p, float (&o)[4]) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4t(T *p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4t<float>(float *p, const float (&v)[4]) {
+    *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4t<bf16_t>(bf16_t *p, const float (&v)[4]) { store4(p, v[0], v[1], v[2], v[3]); }
+
+// Register-resident row: every thread owns RG groups of 4 consecutive columns (H <= 4*RG*blockDim), all of its loads
+// (split-K slabs, residual, bias, norm weights) are issued up front, and the only block-wide step is the reduction of
+// the statistics.  No LDS row buffer.
+#define RN_RG 2
 template <typename T>
 __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, const float *__restrict__ part, int S,
                                                             size_t stride_s, int H, const T *__restrict__ bias,
                                                             const T *__restrict__ w, const T *__restrict__ b,
                                                             float eps, int kind, int mode, T *__restrict__ h) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *xs = reinterpret_cast<float *>(smem);
-    float *red = xs + H;
+    __shared__ float red[32];
     const int row = blockIdx.x;
     T *xr = x + (size_t)row * H;
     T *hr = h + (size_t)row * H;
-    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {     // H % 4 == 0 (checked at model creation)
-        const f32x4 y4 = reduce_part4(part, S, stride_s, (size_t)row * H + i);
+    float v[RN_RG][4], wv[RN_RG][4], bv[RN_RG][4];
+    bool on[RN_RG];
+    f32x4 y4[RN_RG];
+    float xin[RN_RG][4], bi[RN_RG][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float y = y4[j];
-            if (bias) y += to_f(bias[i + j]);
-            const float v = rnd<T>(to_f(xr[i + j]) + rnd<T>(y));
-            xs[i + j] = v;
-            if (mode != RES_POST) xr[i + j] = from_f<T>(v);
-            if (mode == RES_NONE) hr[i + j] = from_f<T>(v);
+    for (int g = 0; g < RN_RG; ++g) {
+        const int i = (threadIdx.x + g * blockDim.x) * 4;
+        on[g] = i < H;
+        if (on[g]) {
+            y4[g] = reduce_part4(part, S, stride_s, (size_t)row * H + i);
+            load4<T>(xr + i, xin[g]);
+            if (bias) load4<T>(bias + i, bi[g]);
+            if (mode != RES_NONE) {
+                load4<T>(w + i, wv[g]);
+                if (kind == NORM_LN) load4<T>(b + i, bv[g]);
+            }
         }
     }
-    __syncthreads();
-    if (mode == RES_PRE) norm_row<T>(xs, H, w, b, eps, kind, red, hr, nullptr);
-    else if (mode == RES_POST) norm_row<T>(xs, H, w, b, eps, kind, red, hr, xr);
+    float a = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < RN_RG; ++g) {
+        if (!on[g]) continue;
+        const int i = (threadIdx.x + g * blockDim.x) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y = y4[g][j];
+            if (bias) y += bi[g][j];
+            v[g][j] = rnd<T>(xin[g][j] + rnd<T>(y));
+            a += v[g][j];
+            a2 += v[g][j] * v[g][j];
+        }
+        if (mode != RES_POST) store4t<T>(xr + i, v[g]);
+        if (mode == RES_NONE) store4t<T>(hr + i, v[g]);
+    }
+    if (mode == RES_NONE) return;
+    float mean = 0.f, r;
+    if (kind == NORM_RMS) {
+        r = rsqrtf(block_sum(a2, red) / (float)H + eps);          // modeling_llama.py:84-89
+    } else {
+        mean = block_sum(a, red) / (float)H;
+        float d2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < RN_RG; ++g)
+            if (on[g])
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[g][j] - mean; d2 += d * d; }
+        r = 1.0f / sqrtf(block_sum(d2, red) / (float)H + eps);
+    }
+#pragma unroll
+    for (int g = 0; g < RN_RG; ++g) {
+        if (!on[g]) continue;
+        const int i = (threadIdx.x + g * blockDim.x) * 4;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = kind == NORM_RMS ? rnd<T>(wv[g][j] * rnd<T>(v[g][j] * r))
+                                    : rnd<T>((v[g][j] - mean) * r * wv[g][j] + bv[g][j]);
+        store4t<T>(hr + i, o);
+        if (mode == RES_POST) store4t<T>(xr + i, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -475,6 +538,20 @@ __device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
     const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
+// 8 storage elements held in registers (as loaded by 16-byte loads) -> fp32
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4 (&r)[sizeof(T) == 2 ? 1 : 2], float (&o)[8]);
+template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 (&r)[1], float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = __uint_as_float(r[0][i] << 16);
+        o[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u);
+    }
+}
+template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], float (&o)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = __uint_as_float(r[0][i]); o[4 + i] = __uint_as_float(r[1][i]); }
+}
+
 #define ATT_TQ 8
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
@@ -501,11 +578,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                strm, pos0, s_hi, max_seq, s_cap, tab.n_groups, tab.row_pos[0], tab.row_pos[1]);
 #endif
 
-    for (int i = tid; i < ATT_TQ * D; i += 256) {
-        const int t = i / D, d = i - t * D;
-        qs[i] = t < nr ? to_f(qbuf[(size_t)(r0 + t) * Hq * D + head * D + d]) : 0.f;
+    // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
+    // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128)
+    constexpr int LPR_ = D / 8, NGRP_ = 256 / LPR_, VPF = 16;
+    u32x4 vpre[VPF][sizeof(T) == 2 ? 1 : 2];
+    {
+        const int dp = tid % LPR_, sg = tid / LPR_;
+#pragma unroll
+        for (int j = 0; j < VPF; ++j) {
+            const int s2 = sg + j * NGRP_;
+            if (s2 < s_hi) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(Vv + (size_t)s2 * D + dp * 8);
+                vpre[j][0] = src[0];
+                if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
+            }
+        }
     }
-    __syncthreads();
+    if constexpr (!(sizeof(T) == 2 && D >= 32)) {                 // the MFMA path reads q straight into registers
+        for (int i = tid; i < ATT_TQ * D; i += 256) {
+            const int t = i / D, d = i - t * D;
+            qs[i] = t < nr ? to_f(qbuf[(size_t)(r0 + t) * Hq * D + head * D + d]) : 0.f;
+        }
+        __syncthreads();
+    }
 
     if constexpr (sizeof(T) == 2 && D >= 32) {
         // bf16: QK^T on the matrix cores.  A = 16 keys x 32 dims straight from the arena, B = q^T (rows >= nr
@@ -603,8 +698,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int t = 0; t < ATT_TQ; ++t)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[t][j] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < VPF; ++jj) {
+            const int s = sg + jj * NGRP;
+            if (s < s_hi) {
+                float v[8];
+                unpack8<T>(vpre[jj], v);
+#pragma unroll
+                for (int t = 0; t < ATT_TQ; ++t) {
+                    const float p = sc[(size_t)t * s_cap + s];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
+                }
+            }
+        }
 #pragma unroll 4
-        for (int s = sg; s < s_hi; s += NGRP) {
+        for (int s = sg + VPF * NGRP; s < s_hi; s += NGRP) {
             float v[8];
             load8(Vv + (size_t)s * D + dp * 8, v);
 #pragma unroll
