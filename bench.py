@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--rng", default="device", choices=["device", "host"],
                     help="device = on-device Philox (throughput mode); host = torch CPU generator in the reference's order")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="time the CPU oracle on a bounded sample (rank 0, N=1)")
-    ap.add_argument("--cpu-max-len", type=int, default=16)
+    ap.add_argument("--cpu-max-len", type=int, default=32)
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="wall budget for the CPU baseline runs")
     ap.add_argument("--cpu-prompt-len", type=int, default=128)
     ap.add_argument("--batch-streams", type=int, default=1,
@@ -317,7 +317,7 @@ def main():
         roofline["op_classes_launches_per_verify"] = {k: v[1] // reps for k, v in prof.items()}
         if "gemm" in prof:
             g_ms = prof["gemm"][0] / reps
-            roofline["gemm_kernel"] = {"name": "gemm_bf16_stream<1,8>", "weight_bytes_per_verify": wbytes,
+            roofline["gemm_kernel"] = {"name": "gemm_bf16_stream<MT=1,UNROLL=4,EPI,NTW=1> (all epilogue variants)", "weight_bytes_per_verify": wbytes,
                                        "ms_per_verify": g_ms, "achieved_GBs": wbytes / (g_ms * 1e-3) / 1e9,
                                        "frac": wbytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 

@@ -612,24 +612,37 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int dk = 0; dk < D / 32; ++dk)
             qf[dk] = mrow < nr ? *reinterpret_cast<const u32x4 *>(qbuf + (size_t)(r0 + mrow) * Hq * D + head * D + dk * 32 + kq)
                                : u32x4{0u, 0u, 0u, 0u};
-        for (int kt = w; kt * 16 < s_hi; kt += 4) {
-            const int key = kt * 16 + mrow;
-            const T *kr = K + (size_t)min(key, s_hi - 1) * D + kq;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // key tiles are taken 4 at a time per wave with all of their K loads issued before the first MFMA
+        // (a plain loop over tiles would pay one memory round trip per tile)
+        for (int kt0 = w; kt0 * 16 < s_hi; kt0 += 16) {
+            u32x4 kf[4][D / 32];
 #pragma unroll
-            for (int dk = 0; dk < D / 32; ++dk) {
-                const u32x4 kf = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                              __builtin_bit_cast(bf16x8, qf[dk]), acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int kt = kt0 + 4 * u;
+                if (kt * 16 < s_hi) {
+                    const T *kr = K + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
+#pragma unroll
+                    for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
+                }
             }
-            if (mrow < ATT_TQ) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int s = kt * 16 + (lane >> 4) * 4 + j;
-                    if (s < s_hi) {
-                        float v = rnd<T>(acc[j]);
-                        if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
-                        sc[(size_t)mrow * s_cap + s] = (s <= pos0 + r0 + mrow) ? v : -INFINITY;
+            for (int u = 0; u < 4; ++u) {
+                const int kt = kt0 + 4 * u;
+                if (kt * 16 >= s_hi) continue;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dk = 0; dk < D / 32; ++dk)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[u][dk]),
+                                                                  __builtin_bit_cast(bf16x8, qf[dk]), acc, 0, 0, 0);
+                if (mrow < ATT_TQ) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int s = kt * 16 + (lane >> 4) * 4 + j;
+                        if (s < s_hi) {
+                            float v = rnd<T>(acc[j]);
+                            if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
+                            sc[(size_t)mrow * s_cap + s] = (s <= pos0 + r0 + mrow) ? v : -INFINITY;
+                        }
                     }
                 }
             }
