@@ -600,3 +600,55 @@ def test_config1_full_size_opt_pair_fp32_vs_oracle(hip):
                                          rng=hip.noise.ReplayNoise(rec.events, "cuda"))
     assert torch.equal(got.cpu(), want)
     assert gd["acc_len"] == wd["acc_len"]
+
+
+def test_error_paths_match_reference_exceptions(hip, capsys):
+    """NaN logits -> RuntimeError('norm logits error') from norm_logits and wrapped as RuntimeError('s') by
+    speculative_sampling (reference utils.py:203-207, speculative_sampling.py:2044-2046), on both loop implementations."""
+    cfg = load_config("tiny-llama-draft")
+    sd = make_state_dict(cfg, 21)
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["lm_head.weight"][7, :] = float("nan")                   # every logit row gets a NaN at token 7
+    good = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    broken = hip.engine.SpecDecModel.from_state_dict(cfg, bad, dtype=torch.float32)
+    prompt = torch.arange(3, 12, dtype=torch.int64)[None].cuda()
+    with pytest.raises(RuntimeError, match="norm logits error"):
+        hip.S.KVCacheModel(broken, 1.0, 20, 0.9)._forward_with_kvcache(prompt)
+    for rng in ("host", "device"):
+        with pytest.raises(RuntimeError, match="^s$"):
+            hip.S.speculative_sampling(prompt, good, broken, 2, None, 8, top_k=20, top_p=0.9, rng=rng)
+        with pytest.raises(RuntimeError, match="^s$"):
+            hip.S.speculative_sampling(prompt, broken, good, 2, None, 8, top_k=20, top_p=0.9, rng=rng)
+    capsys.readouterr()
+    # the engine refuses what it cannot hold instead of writing out of bounds
+    ses = good.new_session(16)
+    with pytest.raises(hip.L.SpecDecError, match="capacity"):
+        ses.forward(torch.zeros(17, dtype=torch.int32, device="cuda"), 1)
+
+
+def test_kvcache_full_history_long_prefill(hip):
+    """Standalone KVCacheModel (full_history, the reference's behaviour): a 150-token prompt is normalised for every
+    position, in chunks, and matches the oracle wrapper's (1, S, V) history."""
+    cfg = load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 12)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    prompt = torch.from_numpy(np.random.default_rng(6).integers(3, cfg.vocab_size, size=(1, 150)))
+    okv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 0.9, 30, 0.95)
+    last = okv._forward_with_kvcache(prompt)
+    kv = hip.S.KVCacheModel(m, 0.9, 30, 0.95)
+    got = kv._forward_with_kvcache(prompt.cuda())
+    assert kv._prob_history.shape == okv._prob_history.shape == (1, 150, cfg.vocab_size)
+    assert float((kv._prob_history.cpu() - okv._prob_history).abs().max()) < 2e-5
+    assert torch.equal(kv._prob_history.cpu() > 0, okv._prob_history > 0)
+    assert float((got.cpu() - last).abs().max()) < 2e-5
+
+
+def test_host_rng_autoregressive_matches_reference_seed(hip):
+    """autoregressive_sampling with the default host RNG reproduces the reference's run under its outer seed."""
+    case = G5_META["ar"][0]
+    cfg = load_config(case["cfg"])
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, make_state_dict(cfg, case["seed"]), dtype=torch.float32)
+    prompt = torch.from_numpy(G5[case["id"] + "_prompt"].astype(np.int64))[None].cuda()
+    torch.manual_seed(77)
+    out = hip.S.autoregressive_sampling(prompt, m, case["N"], case["eos"], **case["kwargs"])
+    np.testing.assert_array_equal(out.cpu().numpy()[0], G5[case["id"] + "_out"])
