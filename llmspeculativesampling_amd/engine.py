@@ -290,21 +290,24 @@ class Session:
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(_lib.PROFILE_CLASS_NAMES) if cnt[i]}
 
 
-_MODEL_CACHE: Dict[int, SpecDecModel] = {}
+import weakref
+
+_MODEL_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()   # HF module -> SpecDecModel (dies with the module)
 
 
 def as_specdec_model(model, dtype: Optional[torch.dtype] = None) -> SpecDecModel:
-    """Accept the engine's own model or an HF module (converted once, cached by id)."""
+    """Accept the engine's own model or an HF module (converted once, cached per module object)."""
     if isinstance(model, SpecDecModel):
         return model
-    key = id(model)
-    if key not in _MODEL_CACHE:
-        if not hasattr(model, "state_dict") or not hasattr(model, "config"):
-            raise TypeError(f"cannot use {type(model).__name__} as a decoder model")
-        if getattr(model.config, "is_encoder_decoder", False):
-            raise NotImplementedError("encoder-decoder models (reference speculative_sampling.py:1946,1958) are out of scope")
-        _MODEL_CACHE[key] = SpecDecModel.from_hf(model, dtype=dtype)
-    return _MODEL_CACHE[key]
+    if not hasattr(model, "state_dict") or not hasattr(model, "config"):
+        raise TypeError(f"cannot use {type(model).__name__} as a decoder model")
+    if getattr(model.config, "is_encoder_decoder", False):
+        raise NotImplementedError("encoder-decoder models (reference speculative_sampling.py:1946,1958) are out of scope")
+    hit = _MODEL_CACHE.get(model)
+    if hit is None:
+        hit = SpecDecModel.from_hf(model, dtype=dtype)
+        _MODEL_CACHE[model] = hit
+    return hit
 
 
 def batch_forward(sessions: List[Session], seqs: List[torch.Tensor], n_new: List[int], n_logits: List[int],

@@ -29,7 +29,7 @@ def bench(name, N, K, M=5, units=None, iters=30):
         Wp.append(o)
     torch.cuda.synchronize()
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-    part = torch.empty(64 * 16 * N, dtype=torch.float32, device="cuda")
+    part = torch.empty(64 * 64 * N, dtype=torch.float32, device="cuda")
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
     S = C.c_int(0)
     st = torch.cuda.current_stream().cuda_stream
