@@ -122,6 +122,18 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
     const char *env = getenv("SD_GEMM_UNITS");
     if (env) {
         S = (atoi(env) + NTL / 2) / NTL;
+    } else if (M > 16) {
+        // many rows: every extra slab costs a write + a read of Mpad*N floats, which at 64 rows rivals the weight bytes
+        // (256*S/K of them), so take the S that minimises (weights + slab traffic) / CU-fill efficiency
+        const double wbytes = (double)N * K * 2.0, slab = 2.0 * (double)align_up(M, 16) * N * 4.0;
+        double best = 1e300;
+        for (int c = 1; c <= max_s && c <= 16; ++c) {
+            const int blocks = NTL * c;
+            if (blocks < 256 && c < max_s && c < 16) continue;
+            const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+            const double cost = (wbytes + slab * c) / eff * (blocks < 768 ? 1.25 : 1.0);   // too few workgroups under-fill the load path
+            if (cost < best) { best = cost; S = c; }
+        }
     } else if (NTL < 1024) {
         // fewest slabs that give >= 1024 workgroups, preferring a workgroup count that fills all 256 CUs evenly
         // (measured on MI355X: 7.5 workgroups per CU runs 10 % slower than 15 per CU, tools/gemm_bench.py)
