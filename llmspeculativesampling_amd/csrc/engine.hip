@@ -323,21 +323,7 @@ static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, 
     // rows beyond one m-tile (prefill, stream-batched verify): every activation fragment a wave loads is reused for
     // NTW weight tiles, because activations and weights share the CU's load path (X:W bytes = 16*MT : 16*NTW)
     const int ntw = gemm_ntw(N, M);
-    if (MT == 1) {
-        static const int variant = getenv("SD_GEMM_VARIANT") ? atoi(getenv("SD_GEMM_VARIANT")) : 0;   // tuning knob (tools/gemm_bench.py)
-        const int blocks = (N / 16) * S;
-        if (variant == 1)
-            hipLaunchKernelGGL((gemm_bf16_stream<1, 2, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
-                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
-        else if (variant == 2)
-            hipLaunchKernelGGL((gemm_bf16_stream<1, 8, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
-                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
-        else if (variant == 3)
-            hipLaunchKernelGGL((gemm_bf16_stream<1, 3, EPI, 1, true>), dim3(blocks), dim3(256), 0, st, (const u32x4 *)W,
-                               (const bf16_t *)X, part, M, Mpad, N, K, S, ksp, e);
-        else
-            launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-    }
+    if (MT == 1) launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
     else if (MT == 2) { if (ntw >= 4) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<2, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else if (MT == 3) { if (ntw == 8) launch_gemm_bf16<3, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);

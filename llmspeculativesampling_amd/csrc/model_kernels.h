@@ -572,11 +572,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     const T *Vv = karena + (size_t)(Hkv + kvh) * max_seq * D;
     const int tid = threadIdx.x;
     const int s_hi = pos0 + r0 + nr;                              // keys visible to the last row of the group
-#ifdef SD_DEBUG_ATTN
-    if (tid == 0 && head == 0 && layer == 0)
-        printf("attn grp %d: r0=%d nr=%d strm=%d pos0=%d s_hi=%d max_seq=%d s_cap=%d n_groups=%d rowpos=%d,%d\n", (int)blockIdx.y, r0, nr,
-               strm, pos0, s_hi, max_seq, s_cap, tab.n_groups, tab.row_pos[0], tab.row_pos[1]);
-#endif
 
     // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
     // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128)

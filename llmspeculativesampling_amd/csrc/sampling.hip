@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict_
     __shared__ uint2 cand_sh[CAND_CAP];
     __shared__ float redf[16];
     __shared__ int redi[16];
-    const int row = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int row = blockIdx.y, b = blockIdx.x, tid = threadIdx.x;
     const float4 *x4 = reinterpret_cast<const float4 *>(logits + (size_t)row * ld_in);
     float4 *o4 = reinterpret_cast<float4 *>(use_tab ? tab.out[blockIdx.y] : out + (size_t)row * ld_out);
     const int V4 = V >> 2, C4 = (V4 + NB_SPLIT - 1) / NB_SPLIT;

@@ -208,9 +208,6 @@ class SpecDecModel:
         m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
         return m
 
-    def export_state_dict(self) -> Dict[str, torch.Tensor]:
-        raise NotImplementedError
-
     def new_session(self, max_seq: int, max_rows: int = MAX_ROWS_PER_FORWARD) -> "Session":
         return Session(self, max_seq, max_rows)
 

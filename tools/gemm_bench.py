@@ -67,5 +67,3 @@ if __name__ == "__main__":
                 for M in (40, 64):
                     print("NTW", ntw, end=" ")
                     bench(n, *SHAPES[n], M=M)
-    if sys.argv[1:] == ["variants"]:
-        pass
