@@ -35,6 +35,7 @@ struct sd_session {
     char *scratch;
     // carved scratch
     void *x, *h, *qbuf, *attn, *act, *ebuf;
+    float *attn_part;   // [groups*splits <= 64][Hq][TQ][D+2] partial attention sums of the split-key path
     float *part;
     size_t part_floats;
     // profiling
@@ -175,7 +176,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, h, q, attn, act, e, part, total, part_floats;
+    size_t x, h, q, attn, act, e, apart, part, total, part_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -190,6 +191,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.attn = take((size_t)rows * c.hidden * es);
     p.act = take((size_t)rows * c.inter * es);
     p.e = take((size_t)rows * ed * es);
+    p.apart = take((size_t)64 * c.n_heads * 8 * (c.head_dim + 2) * sizeof(float));
     size_t pf = 0;
     pf = std::max(pf, gemm_part_floats(c, qkv_cols(c), c.hidden, rows));
     pf = std::max(pf, gemm_part_floats(c, c.hidden, c.hidden, rows));
@@ -231,6 +233,7 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->attn = s->scratch + p.attn;
     s->act = s->scratch + p.act;
     s->ebuf = s->scratch + p.e;
+    s->attn_part = (float *)(s->scratch + p.apart);
     s->part = (float *)(s->scratch + p.part);
     s->part_floats = p.part_floats;
     s->prof_on = 0;
@@ -375,19 +378,46 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
     return SD_OK;
 }
 
+// keys per workgroup above which a group's keys are cut over several workgroups (and merged by attn_combine_kernel)
+#define ATT_SPLIT_KEYS 384
+#define ATT_MAX_PARTS 64          // groups * splits the partial buffer is sized for
+
 template <typename T, int D>
-static void launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, hipStream_t st) {
+static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
-    const int s_cap = (int)align_up(s_max, 64);
-    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    // 160 KiB per workgroup less the kernel's static LDS (the split path's per-row max / denominator)
+    const size_t lds_max = 160 * 1024 - 512;
+    auto lds_for = [&](int nsplit, int *s_cap) {
+        const int keys = nsplit > 1 ? (((s_max + nsplit - 1) / nsplit + 15) & ~15) : s_max;
+        *s_cap = (int)align_up(keys, 64);
+        return sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * *s_cap);
+    };
+    static const int split_keys = getenv("SD_ATTN_SPLIT_KEYS") ? atoi(getenv("SD_ATTN_SPLIT_KEYS")) : ATT_SPLIT_KEYS;
+    static const int keys_per = getenv("SD_ATTN_KEYS_PER_SPLIT") ? atoi(getenv("SD_ATTN_KEYS_PER_SPLIT")) : 256;
+    int nsplit = 1, s_cap;
+    if (s_max > split_keys) {
+        nsplit = std::min(8, (s_max + keys_per - 1) / keys_per);
+        while (nsplit > 1 && nsplit * tab.n_groups > ATT_MAX_PARTS) --nsplit;
+    }
+    // very long contexts: more, smaller chunks until one chunk's score rows fit the LDS
+    while (lds_for(nsplit, &s_cap) > lds_max && (nsplit + 1) * tab.n_groups <= ATT_MAX_PARTS) ++nsplit;
+    const size_t lds = lds_for(nsplit, &s_cap);
+    if (lds > lds_max) {
+        sd_set_error("attention: %d keys x %d row groups exceed the LDS score tile", s_max, tab.n_groups);
+        return SD_ERR_CAPACITY;
+    }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, tab.n_groups), dim3(256), lds, st, q, tab, layer, out,
-                       c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap);
+    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer, out,
+                       c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
+    if (nsplit > 1)
+        hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3(c.n_heads, tab.n_groups), dim3(128), 0, st,
+                           (const float *)s->attn_part, tab, out, c.n_heads, nsplit);
+    return SD_OK;
 }
 
 template <typename T>
@@ -461,11 +491,12 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         {
             ProfScope ps(s, PC_ATTN, st);
             switch (D) {
-                case 16: launch_attn<T, 16>(s, qb, tab, l, at, s_max, st); break;
-                case 32: launch_attn<T, 32>(s, qb, tab, l, at, s_max, st); break;
-                case 64: launch_attn<T, 64>(s, qb, tab, l, at, s_max, st); break;
-                default: launch_attn<T, 128>(s, qb, tab, l, at, s_max, st); break;
+                case 16: rc = launch_attn<T, 16>(s, qb, tab, l, at, s_max, st); break;
+                case 32: rc = launch_attn<T, 32>(s, qb, tab, l, at, s_max, st); break;
+                case 64: rc = launch_attn<T, 64>(s, qb, tab, l, at, s_max, st); break;
+                default: rc = launch_attn<T, 128>(s, qb, tab, l, at, s_max, st); break;
             }
+            if (rc != SD_OK) return rc;
             SD_LAUNCH_CHECK();
         }
         // output projection + residual (+ norm feeding the MLP)

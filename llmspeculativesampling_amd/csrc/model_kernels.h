@@ -556,7 +556,7 @@ template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
                                                   T *__restrict__ out, int Hq, int Hkv, int arch,
-                                                  float inv_sqrt_d, int s_cap) {
+                                                  float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     float *red = qs + ATT_TQ * D;                                 // [4 waves][TQ][D]
@@ -568,10 +568,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     const int pos0 = tab.grp_pos[blockIdx.y] - r0;
     const int kvh = head / (Hq / Hkv);
     const T *karena = (const T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
-    const T *K = karena + (size_t)kvh * max_seq * D;
-    const T *Vv = karena + (size_t)(Hkv + kvh) * max_seq * D;
     const int tid = threadIdx.x;
-    const int s_hi = pos0 + r0 + nr;                              // keys visible to the last row of the group
+    // long contexts (nsplit > 1, "flash-decoding"): workgroup z takes keys [kb, kb + s_hi) of the group's visible keys and
+    // leaves un-normalised partial sums (+ running max and denominator) for attn_combine_kernel; nsplit == 1 is the
+    // whole range.  From here on key indices are local to the chunk.
+    const int s_all = pos0 + r0 + nr;                             // keys visible to the last row of the group
+    const int chunk = nsplit > 1 ? (((s_all + nsplit - 1) / nsplit + 15) & ~15) : s_all;
+    const int kb = nsplit > 1 ? (int)blockIdx.z * chunk : 0;
+    const int s_hi = max(0, min(s_all, kb + chunk) - kb);
+    const int vis0 = pos0 + r0 - kb;                              // local index of the last key row t = 0 may see
+    const T *K = karena + ((size_t)kvh * max_seq + kb) * D;
+    const T *Vv = karena + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
+    __shared__ float ml[ATT_TQ][2];
 
     // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
     // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128)
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                         if (s < s_hi) {
                             float v = rnd<T>(acc[j]);
                             if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
-                            sc[(size_t)mrow * s_cap + s] = (s <= pos0 + r0 + mrow) ? v : -INFINITY;
+                            sc[(size_t)mrow * s_cap + s] = (s <= vis0 + mrow) ? v : -INFINITY;
                         }
                     }
                 }
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int t = 0; t < ATT_TQ; ++t) {
             float v = rnd<T>(acc[t]);                             // matmul result in T
             if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d) ;  // scale after the matmul (modeling_llama.py:346)
-            sc[(size_t)t * s_cap + s] = (s <= pos0 + r0 + t) ? v : -INFINITY;
+            sc[(size_t)t * s_cap + s] = (s <= vis0 + t) ? v : -INFINITY;
         }
     }
     __syncthreads();
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         const int w = tid >> 6, lane = tid & 63;
         for (int t = w; t < nr; t += 4) {
             float *row = sc + (size_t)t * s_cap;
-            const int len = pos0 + r0 + t + 1;
+            const int len = max(0, min(s_hi, vis0 + t + 1));
             float m = -INFINITY;
             for (int s = lane; s < len; s += 64) m = fmaxf(m, row[s]);
             m = wave_max(m);
@@ -690,7 +698,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 sum += e;
             }
             sum = wave_sum(sum);
-            for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? rnd<T>(row[s] / sum) : 0.f;
+            if (nsplit > 1) {                                     // keep exp(score - local max); the combine normalises
+                for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? row[s] : 0.f;
+                if (lane == 0) { ml[t][0] = m; ml[t][1] = sum; }
+            } else {
+                for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? rnd<T>(row[s] / sum) : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -747,12 +760,47 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         (void)GPW;
     }
     __syncthreads();
+    if (nsplit > 1) {
+        float *pz = partial + (((size_t)blockIdx.y * Hq + head) * nsplit + blockIdx.z) * ATT_TQ * (D + 2);
+        for (int i = tid; i < nr * D; i += 256) {
+            const int t = i / D, d = i - t * D;
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+            pz[(size_t)t * (D + 2) + d] = a;
+        }
+        if (tid < nr) { pz[(size_t)tid * (D + 2) + D] = ml[tid][0]; pz[(size_t)tid * (D + 2) + D + 1] = ml[tid][1]; }
+        return;
+    }
     for (int i = tid; i < nr * D; i += 256) {
         const int t = i / D, d = i - t * D;
         float a = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
         out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a);
+    }
+}
+
+// out = sum_z acc_z * exp(m_z - M) / sum_z l_z * exp(m_z - M): merges the nsplit key chunks of one (head, group)
+template <typename T, int D>
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restrict__ partial, RowTab tab,
+                                                          T *__restrict__ out, int Hq, int nsplit) {
+    const int head = blockIdx.x, r0 = tab.grp_row0[blockIdx.y], nr = tab.grp_n[blockIdx.y];
+    const float *pz = partial + ((size_t)blockIdx.y * Hq + head) * nsplit * ATT_TQ * (D + 2);
+    for (int i = threadIdx.x; i < nr * D; i += 128) {
+        const int t = i / D, d = i - t * D;
+        float M = -INFINITY;
+        for (int z = 0; z < nsplit; ++z) M = fmaxf(M, pz[((size_t)z * ATT_TQ + t) * (D + 2) + D]);
+        float L = 0.f, a = 0.f;
+        for (int z = 0; z < nsplit; ++z) {
+            const float *r = pz + ((size_t)z * ATT_TQ + t) * (D + 2);
+            const float m = r[D];
+            if (m == -INFINITY) continue;                         // chunk with no visible key for this row
+            const float w = expf(m - M);
+            L += r[D + 1] * w;
+            a += r[d] * w;
+        }
+        out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a / L);
     }
 }
 

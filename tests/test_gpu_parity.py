@@ -451,6 +451,34 @@ def test_forward_production_head_dims_vs_oracle(hip, name, dtype):
     assert float((v.float().cpu() - ov.float()).abs().max()) <= ktol * max(1.0, float(ov.float().abs().max()))
 
 
+@pytest.mark.parametrize("name", ["llama_d128", "llama_d64_gqa", "opt_d32_post"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_forward_long_context_split_keys_vs_oracle(hip, name, dtype):
+    """Contexts past 384 keys take the split-key attention path (each row group's keys cut over up to 8 workgroups,
+    merged by attn_combine_kernel): a 900-token prompt in 64-row chunks, then steps of 1, 5 and 9 rows, against the
+    oracle forward.  fp32 1e-3 (north_star).  bf16: on this path the softmax weights are not rounded to bf16 before
+    P.V (the reference rounds them), so the bound is the same few-ulps-of-logit-scale one as the short-context test."""
+    from llmspeculativesampling_amd.config import ModelConfig
+    cfg = ModelConfig(**dict(MID_CFGS[name], max_position_embeddings=1024))
+    sd = make_state_dict(cfg, 78, dtype=dtype)
+    om = oracle.RefCausalLM(cfg, sd)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    ses = m.new_session(960)
+    ids = torch.from_numpy(np.random.default_rng(10).integers(3, cfg.vocab_size, size=(1, 915)))
+    past, pos = None, 0
+    for q in (900, 1, 5, 9):
+        chunk = ids[:, pos:pos + q]
+        o = om(chunk, past_key_values=past)
+        past = o.past_key_values
+        nl = min(q, 9)
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), nl).cpu()
+        want = o.logits.float()[0, -nl:]
+        scale = float(want.abs().max())
+        tol = 1e-3 if dtype == torch.float32 else 0.04 * scale
+        assert float((got - want).abs().max()) <= tol, (name, q, float((got - want).abs().max()), scale)
+        pos += q
+
+
 def test_speculative_bf16_statistics_vs_oracle(hip):
     """bf16 end to end (fused epilogues, MFMA attention): same recorded noise into the oracle's bf16 CPU run and the
     HIP run.  bf16 rounding-order differences may flip an occasional token, so the bar is statistical: accept-length
