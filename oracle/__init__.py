@@ -21,3 +21,4 @@ from .sampling_ref import norm_logits, top_k_top_p_filter, sample, max_fn  # noq
 from .models_ref import RefCausalLM  # noqa: F401
 from .kvcache_ref import RefKVCacheModel  # noqa: F401
 from .specdec_ref import speculative_sampling, autoregressive_sampling  # noqa: F401
+from .multi_ref import multi_speculative_sampling  # noqa: F401

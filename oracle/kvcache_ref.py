@@ -1,8 +1,11 @@
 """Oracle KV-cache wrapper (test infrastructure, see oracle/__init__.py).
 
-Restates the batch-1, decoder-only core of reference sampling/kvcache_model.py:
+Restates the decoder-only core of reference sampling/kvcache_model.py:
 __init__ :24-36, _forward_with_kvcache :141-252, _generate_with_kvcache :255-298,
-generate :300-310, rollback :359-436 (choice=None branch).
+generate :300-310, rollback :359-436 (choice=None and integer-choice branches).
+Batch 1 on the north-star path; the ``multi`` / ``strategy="iid"`` / ``choice`` parts
+(cache replication :180-200, :239-244, repeat :273-276, rollback :390-396, :433-436)
+serve multi_speculative_sampling (oracle/multi_ref.py).
 """
 from __future__ import annotations
 
@@ -43,27 +46,44 @@ class RefKVCacheModel:
             self._prob_history = self._normalise_rows(out.logits)
         else:
             cached = self._past_key_values[0][0].shape[2]                 # (:175)
+            width = input_ids.size(0)
+            if self._past_key_values[0][0].size(0) < width:               # one cached row, width inputs (:180-192)
+                self._past_key_values = [tuple(t.repeat(width, 1, 1, 1) for t in kv) for kv in self._past_key_values]
             fresh = input_ids[:, cached:]                                 # (:206)
             out = self._model(fresh, past_key_values=self._past_key_values, use_cache=True)
             self.rows_fed.append(fresh.shape[1])
             t1 = process_time_ns()
-            self._prob_history = torch.cat([self._prob_history, self._normalise_rows(out.logits)], dim=1)
+            fresh_probs = self._normalise_rows(out.logits)
+            if self._prob_history.size(0) < width:                        # (:239-242)
+                self._prob_history = self._prob_history.repeat(int(width / self._prob_history.size(0)), 1, 1)
+            self._prob_history = torch.cat([self._prob_history, fresh_probs], dim=1)
         self._past_key_values = out.past_key_values
         self.forward_time_dict["_model_time"] += t1 - t0
         self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
         return self._prob_history[:, -1, :]
 
     @torch.no_grad()
-    def generate(self, input: torch.Tensor, gamma: int) -> torch.Tensor:
+    def generate(self, input: torch.Tensor, gamma: int, multi: int = 1, strategy: str = "beam") -> torch.Tensor:
         x = input
+        if strategy == "iid" and multi > 1:                               # (:273-274)
+            x = x.repeat(multi, 1)
+        elif multi > 1:
+            raise NotImplementedError                                     # (:286-287) beam is served elsewhere
         for _ in range(gamma):                                            # (:279-293)
             q = self._forward_with_kvcache(x)
             x = torch.cat((x, sample(q, self.noise)), dim=1)
         return x
 
     @torch.no_grad()
-    def rollback(self, end_pos: int):
+    def rollback(self, end_pos: int, choice=None):
         assert self._past_key_values
-        self._past_key_values = [(k[:, :, :end_pos, :], v[:, :, :end_pos, :]) for k, v in self._past_key_values]
-        if self._prob_history is not None:
-            self._prob_history = self._prob_history[:, :end_pos, :]
+        if choice is None:
+            self._past_key_values = [(k[:, :, :end_pos, :], v[:, :, :end_pos, :]) for k, v in self._past_key_values]
+            if self._prob_history is not None:
+                self._prob_history = self._prob_history[:, :end_pos, :]
+        else:                                                             # integer choice (:390-392, :433-434)
+            c = int(choice)
+            self._past_key_values = [(k[c:c + 1, :, :end_pos, :], v[c:c + 1, :, :end_pos, :])
+                                     for k, v in self._past_key_values]
+            if self._prob_history is not None:
+                self._prob_history = self._prob_history[c:c + 1, :end_pos, :]

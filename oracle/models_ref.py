@@ -7,7 +7,8 @@ Functional torch-CPU restatements of the two model families the reference runs
   OPT:   reference sampling/models/modeling_opt.py:864-997 -> 561-759 -> 303-378 -> 160-278
 
 Weights come in as an HF-named state dict; the KV cache is the reference's
-tuple layout, one (k, v) pair of shape (1, H_kv, S, D) per layer.  Every
+tuple layout, one (k, v) pair of shape (B, H_kv, S, D) per layer (B = 1 on the
+north-star path).  Every
 rounding point of the reference (per-op results in the weight dtype, fp32
 RMSNorm / softmax islands) is kept so that a bf16 run rounds where the
 reference's would.
@@ -57,7 +58,7 @@ def _rot_half(x):
 def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV]):
     dt = sd["model.embed_tokens.weight"].dtype
     H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    q_len = ids.shape[1]
+    B, q_len = ids.shape          # B > 1 only for the width-w drafts of multi_speculative_sampling (oracle/multi_ref.py)
     n_past = past[0][0].shape[2] if past else 0
     x = F.embedding(ids, sd["model.embed_tokens.weight"])
     cos, sin = _rope_tables(D, n_past + q_len, cfg.rope_theta, dt)
@@ -67,9 +68,9 @@ def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Opt
     for li in range(cfg.num_hidden_layers):
         p = f"model.layers.{li}."
         h = _rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_norm_eps)
-        q = F.linear(h, sd[p + "self_attn.q_proj.weight"]).view(1, q_len, H, D).transpose(1, 2)
-        k = F.linear(h, sd[p + "self_attn.k_proj.weight"]).view(1, q_len, Hkv, D).transpose(1, 2)
-        v = F.linear(h, sd[p + "self_attn.v_proj.weight"]).view(1, q_len, Hkv, D).transpose(1, 2)
+        q = F.linear(h, sd[p + "self_attn.q_proj.weight"]).view(B, q_len, H, D).transpose(1, 2)
+        k = F.linear(h, sd[p + "self_attn.k_proj.weight"]).view(B, q_len, Hkv, D).transpose(1, 2)
+        v = F.linear(h, sd[p + "self_attn.v_proj.weight"]).view(B, q_len, Hkv, D).transpose(1, 2)
         q = q * cos + _rot_half(q) * sin
         k = k * cos + _rot_half(k) * sin
         if past:
@@ -78,12 +79,12 @@ def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Opt
         new_past.append((k, v))
         if H != Hkv:                                   # repeat_kv, modeling_llama.py:225-234
             rep = H // Hkv
-            k = k[:, :, None].expand(1, Hkv, rep, k.shape[2], D).reshape(1, H, -1, D)
-            v = v[:, :, None].expand(1, Hkv, rep, v.shape[2], D).reshape(1, H, -1, D)
+            k = k[:, :, None].expand(B, Hkv, rep, k.shape[2], D).reshape(B, H, -1, D)
+            v = v[:, :, None].expand(B, Hkv, rep, v.shape[2], D).reshape(B, H, -1, D)
         s = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(D)      # scale after the matmul (:346)
         s = s + bias
         a = F.softmax(s, dim=-1, dtype=torch.float32).to(dt)        # fp32 softmax, cast back (:371)
-        o = torch.matmul(a, v).transpose(1, 2).reshape(1, q_len, H * D)
+        o = torch.matmul(a, v).transpose(1, 2).reshape(B, q_len, H * D)
         x = x + F.linear(o, sd[p + "self_attn.o_proj.weight"])
         h = _rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
         g = F.silu(F.linear(h, sd[p + "mlp.gate_proj.weight"])) * F.linear(h, sd[p + "mlp.up_proj.weight"])
@@ -99,7 +100,7 @@ def opt_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optio
     d = "model.decoder."
     dt = sd[d + "embed_tokens.weight"].dtype
     H, D, hid = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size
-    q_len = ids.shape[1]
+    B, q_len = ids.shape
     n_past = past[0][0].shape[2] if past else 0
     x = F.embedding(ids, sd[d + "embed_tokens.weight"])
     # learned positions, offset 2 (modeling_opt.py:98-124); an all-ones mask makes them n_past..n_past+q-1
@@ -120,21 +121,21 @@ def opt_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optio
         q = F.linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]) * scaling   # pre-scaled q (:178)
         k = F.linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])
         v = F.linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])
-        q = q.view(1, q_len, H, D).transpose(1, 2)
-        k = k.view(1, q_len, H, D).transpose(1, 2)
-        v = v.view(1, q_len, H, D).transpose(1, 2)
+        q = q.view(B, q_len, H, D).transpose(1, 2)
+        k = k.view(B, q_len, H, D).transpose(1, 2)
+        v = v.view(B, q_len, H, D).transpose(1, 2)
         if past:
             k = torch.cat([past[li][0], k], dim=2)
             v = torch.cat([past[li][1], v], dim=2)
         new_past.append((k, v))
-        s = torch.bmm(q.reshape(H, q_len, D), k.reshape(H, -1, D).transpose(1, 2)).view(1, H, q_len, -1)
+        s = torch.bmm(q.reshape(B * H, q_len, D), k.reshape(B * H, -1, D).transpose(1, 2)).view(B, H, q_len, -1)
         s = torch.max(s + bias, torch.tensor(torch.finfo(dt).min))  # mask then clamp (:228-231)
         if dt == torch.float16:                                     # fp32 softmax only for fp16 (:235-238)
             a = F.softmax(s, dim=-1, dtype=torch.float32).to(dt)
         else:
             a = F.softmax(s, dim=-1)
-        o = torch.bmm(a.view(H, q_len, -1), v.reshape(H, -1, D)).view(1, H, q_len, D)
-        o = o.transpose(1, 2).reshape(1, q_len, hid)
+        o = torch.bmm(a.view(B * H, q_len, -1), v.reshape(B * H, -1, D)).view(B, H, q_len, D)
+        o = o.transpose(1, 2).reshape(B, q_len, hid)
         x = res + F.linear(o, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
         if not pre:
             x = F.layer_norm(x, (hid,), sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], eps)

@@ -44,20 +44,22 @@ def norm_logits(logits: torch.Tensor, temperature: float, top_k: float, top_p: f
 def sample(probs: torch.Tensor, noise=None) -> torch.Tensor:
     """reference utils.py:213-233 with num_samples == 1.
 
-    ``torch.multinomial(p, 1)`` on CPU: validity checks, then argmax(p / q) with
-    q ~ Exp(1)^V drawn from the generator.  Invalid rows raise *before* any draw,
-    so the noise stream is untouched when the reference's residual fallback fires
-    (speculative_sampling.py:2007-2010)."""
+    ``torch.multinomial(p, 1)`` on CPU: validity checks, then argmax(p / q) per row with
+    q ~ Exp(1)^(rows x V) drawn from the generator in ONE call.  Invalid input raises *before*
+    any draw, so the noise stream is untouched when the reference's residual fallback fires
+    (speculative_sampling.py:2007-2010).  Rows > 1 only occur in multi_speculative_sampling."""
     noise = noise or TorchGlobalNoise()
-    assert probs.dim() == 2 and probs.size(0) == 1
+    assert probs.dim() == 2
     pmax, pmin = probs.max(), probs.min()
-    if not bool((pmax < float("inf")) & (pmin >= 0)) or bool(probs.sum(1) == 0):
+    if not bool((pmax < float("inf")) & (pmin >= 0)) or bool((probs.sum(1) == 0).any()):
         raise RuntimeError("prob error")
     q = noise.exponential(probs)
     idx = torch.argmax(probs / q, dim=-1, keepdim=True)
-    # utils.py:228-230: a draw that landed on a (near-)zero entry is replaced by the mode
-    if bool((torch.gather(probs, -1, idx) < 1e-9).any()):
-        idx = torch.argmax(probs).reshape(1, 1)
+    # utils.py:228-230: a draw that landed on a (near-)zero entry is replaced by the mode - of the FLATTENED
+    # tensor (torch.argmax without dim), which for one row is that row's mode
+    mask = torch.gather(probs, -1, idx) < 1e-9
+    if bool(mask.any()):
+        idx[mask] = torch.argmax(probs).item()
     return idx
 
 

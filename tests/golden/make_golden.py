@@ -69,7 +69,7 @@ EVENTS = []
 
 
 def _multinomial(p, num_samples=1, replacement=False, **kw):
-    assert num_samples == 1
+    assert num_samples == 1 and p.dim() == 2            # (1, V) rows; (width, V) in multi_speculative_sampling
     st = torch.get_rng_state()
     e = torch.empty_like(p).exponential_(1)
     torch.set_rng_state(st)
@@ -115,6 +115,18 @@ def pack_events(ev):
     return dict(kinds=kinds,
                 exp=np.stack(exps).astype(np.float32) if exps else np.zeros((0, 0), np.float32),
                 uni=np.array(unis, dtype=np.float32), seed=np.array(seeds, dtype=np.int64))
+
+
+def pack_events_ragged(ev):
+    """As pack_events, for streams whose Exp(1) draws differ in size ((width, V) and (1, V))."""
+    kinds = np.array([{"exp": 0, "uni": 1, "seed": 2}[k] for k, _ in ev], dtype=np.uint8)
+    exps = [v.float().numpy().reshape(-1) for k, v in ev if k == "exp"]
+    return dict(kinds=kinds,
+                expflat=np.concatenate(exps).astype(np.float32) if exps else np.zeros(0, np.float32),
+                exprows=np.array([v.shape[0] for k, v in ev if k == "exp"], dtype=np.int32),
+                expsize=np.array([e.size for e in exps], dtype=np.int64),
+                uni=np.array([float(v) for k, v in ev if k == "uni"], dtype=np.float32),
+                seed=np.array([v for k, v in ev if k == "seed"], dtype=np.int64))
 
 
 # --------------------------------------------------------------------------- reference models
@@ -487,6 +499,85 @@ def g6_logits():
     print("G6:", len(cases), "cases")
 
 
+def g7_multi():
+    """multi_speculative_sampling(strategy='iid') token traces of the reference's own model classes
+    (SURVEY.md section 8(f) rank 2): width-w drafts, batched target forward, rollback(end, choice)."""
+    ref_multi = ref_ss.multi_speculative_sampling
+    cases, blobs = [], {}
+    specs = [
+        # id, draft cfg, draft seed, target cfg, target spec, width, kwargs
+        ("m_llama_corr", "tiny-llama-target", 11, "tiny-llama-target", ("perturb", 12, 0.12), 3, dict(top_k=20, top_p=0.9)),
+        ("m_llama_same", "tiny-llama-target", 11, "tiny-llama-target", ("same",), 2, dict(top_k=20, top_p=0.9)),
+        ("m_llama_unrelated", "tiny-llama-draft", 21, "tiny-llama-target", ("seed", 22), 4, dict(top_k=20, top_p=0.9, gamma=3)),
+        ("m_llama_seeded", "tiny-llama-target", 11, "tiny-llama-target", ("perturb", 12, 0.2), 3, dict(top_k=20, top_p=0.9, random_seed=42)),
+        ("m_llama_gqa_w1", "tiny-llama-gqa", 31, "tiny-llama-gqa", ("perturb", 32, 0.1), 1, dict(top_k=10, top_p=0.95, temperature=0.8)),
+        ("m_opt_post_pair", "tiny-opt-pre", 41, "tiny-opt-post", ("seed", 43), 3, dict(top_k=20, top_p=0.9, gamma=2)),
+        ("m_opt_pre_corr", "tiny-opt-pre", 41, "tiny-opt-pre", ("perturb", 42, 0.1), 2, dict(top_k=0, top_p=0.9)),
+    ]
+    for cid, (name, dcfg_n, dseed, tcfg_n, tspec, width, kw) in enumerate(specs):
+        dcfg, tcfg = load_config(dcfg_n), load_config(tcfg_n)
+        dsd = make_state_dict(dcfg, dseed)
+        tsd = dsd if tspec[0] == "same" else (perturb_state_dict(dsd, tspec[1], tspec[2]) if tspec[0] == "perturb"
+                                              else make_state_dict(tcfg, tspec[1]))
+        dm, tm = ref_model(dcfg, dsd), ref_model(tcfg, tsd)
+        rng = np.random.default_rng([7000, cid])
+        L = 8 + cid
+        prompt = torch.from_numpy(rng.integers(3, dcfg.vocab_size, size=(1, L)))
+        eos = 2
+        _real_seed(321 + cid)
+        capture_on()
+        out, d = ref_multi(prompt, dm, tm, eos_token_id=eos, pad_token_id=None, max_len=14, width=width,
+                           strategy="iid", details=True, **kw)
+        ev = capture_off()
+        od, ot = oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd)
+        ro = oracle.multi_speculative_sampling(prompt, od, ot, eos, None, 14, width=width, strategy="iid",
+                                               details=True, noise=oracle.RecordedNoise(ev), **kw)
+        assert torch.equal(ro[0], out), ("oracle != reference (G7)", name, ro[0], out)
+        assert ro[1]["acc_len"] == d["acc_len"] and abs(ro[1]["acc_rate"] - d["acc_rate"]) < 1e-12
+        for k2, v in pack_events_ragged(ev).items():
+            blobs[f"{name}_{k2}"] = v
+        blobs[f"{name}_out"] = out.numpy()[0].astype(np.int32)
+        blobs[f"{name}_prompt"] = prompt.numpy()[0].astype(np.int32)
+        cases.append(dict(id=name, draft_cfg=dcfg_n, draft_seed=dseed, target_cfg=tcfg_n, target_spec=list(tspec),
+                          width=width, kwargs=kw, eos=eos, max_len=14, L=L, outer_seed=321 + cid,
+                          acc_len=d["acc_len"], acc_rate=float(d["acc_rate"]),
+                          target_call_times=d["target_call_times"], approx_call_times=d["approx_call_times"],
+                          rows_fed_draft=ro[1]["_rows_fed_draft"], rows_fed_target=ro[1]["_rows_fed_target"],
+                          out_len=int(out.shape[1])))
+        print("  G7", name, "width", width, "out_len", out.shape[1], "acc_len", d["acc_len"])
+    # EOS stop: a token the first trace is known to emit becomes EOS
+    base_out, L0 = blobs["m_llama_corr_out"], cases[0]["L"]
+    eos_tok = int(base_out[L0 + 4])
+    dcfg = load_config("tiny-llama-target")
+    dsd = make_state_dict(dcfg, 11)
+    tsd = perturb_state_dict(dsd, 12, 0.12)
+    dm, tm = ref_model(dcfg, dsd), ref_model(dcfg, tsd)
+    prompt = torch.from_numpy(blobs["m_llama_corr_prompt"].astype(np.int64))[None].clone()
+    _real_seed(321)
+    capture_on()
+    out, d = ref_multi(prompt, dm, tm, eos_token_id=eos_tok, pad_token_id=None, max_len=14, width=3, strategy="iid",
+                       top_k=20, top_p=0.9, details=True)
+    ev = capture_off()
+    ro = oracle.multi_speculative_sampling(prompt, oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(dcfg, tsd), eos_tok,
+                                           None, 14, width=3, strategy="iid", top_k=20, top_p=0.9, details=True,
+                                           noise=oracle.RecordedNoise(ev))
+    assert torch.equal(ro[0], out), "oracle != reference (G7 eos)"
+    for k2, v in pack_events_ragged(ev).items():
+        blobs[f"m_eos_{k2}"] = v
+    blobs["m_eos_out"] = out.numpy()[0].astype(np.int32)
+    blobs["m_eos_prompt"] = prompt.numpy()[0].astype(np.int32)
+    cases.append(dict(id="m_eos", draft_cfg="tiny-llama-target", draft_seed=11, target_cfg="tiny-llama-target",
+                      target_spec=["perturb", 12, 0.12], width=3, kwargs=dict(top_k=20, top_p=0.9), eos=eos_tok,
+                      max_len=14, L=int(prompt.shape[1]), outer_seed=321, acc_len=d["acc_len"],
+                      acc_rate=float(d["acc_rate"]), target_call_times=d["target_call_times"],
+                      approx_call_times=d["approx_call_times"], rows_fed_draft=ro[1]["_rows_fed_draft"],
+                      rows_fed_target=ro[1]["_rows_fed_target"], out_len=int(out.shape[1])))
+    print("  G7 m_eos out_len", out.shape[1], "eos", eos_tok)
+    np.savez_compressed(os.path.join(HERE, "g7_multi.npz"), **blobs)
+    json.dump(cases, open(os.path.join(HERE, "g7_multi.json"), "w"), indent=0)
+    print("G7:", len(cases), "multi traces")
+
+
 def misc():
     """Facts the design leans on, recorded from the live reference environment."""
     facts = {"torch": torch.__version__, "transformers": transformers.__version__}
@@ -501,11 +592,8 @@ def misc():
 
 
 if __name__ == "__main__":
-    misc()
-    g1_norm_logits()
-    g2_sample_maxfn()
-    g4_accept()
-    g5_traces()
-    g6_logits()
+    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi)
+    for name in (sys.argv[1:] or list(todo)):             # e.g. `make_golden.py g7` regenerates one fixture set
+        todo[name]()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("fixtures total bytes:", tot)

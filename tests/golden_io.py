@@ -38,6 +38,29 @@ def events(blobs, prefix):
     return out
 
 
+def events_ragged(blobs, prefix):
+    """G7 streams: Exp(1) draws of shape (rows, V) - (width, V) for the batched draft / target samples, (1, V) for
+    the residual-or-bonus sample - stored flat with their row counts."""
+    kinds = blobs[prefix + "_kinds"]
+    flat, rows, size = blobs[prefix + "_expflat"], blobs[prefix + "_exprows"], blobs[prefix + "_expsize"]
+    uni, seed = blobs[prefix + "_uni"], blobs[prefix + "_seed"]
+    ie = iu = isd = off = 0
+    out = []
+    for k in kinds:
+        if k == 0:
+            n = int(size[ie])
+            out.append(("exp", torch.from_numpy(flat[off:off + n].reshape(int(rows[ie]), -1).copy())))
+            off += n
+            ie += 1
+        elif k == 1:
+            out.append(("uni", torch.tensor([uni[iu]], dtype=torch.float32)))
+            iu += 1
+        else:
+            out.append(("seed", int(seed[isd])))
+            isd += 1
+    return out
+
+
 def dense_from_sparse(V, idx, val):
     p = np.zeros(V, dtype=np.float32)
     p[idx] = val

@@ -168,6 +168,36 @@ def test_speculative_live_generator_seeded_quirk():
     np.testing.assert_array_equal(out.numpy()[0], G5["llama_seeded_out"])
 
 
+G7_META, G7 = load("g7_multi")
+
+
+@pytest.mark.parametrize("case", G7_META, ids=[c["id"] for c in G7_META])
+def test_multi_speculative_trace_golden(case):
+    """multi_speculative_sampling(strategy="iid"): the oracle, replaying the reference's
+    recorded noise, reproduces its tokens, acc_len list, acc_rate, call counts and consumes the stream exactly."""
+    from golden_io import events_ragged
+    dcfg, dsd, tcfg, tsd = model_pair(case)
+    prompt = torch.from_numpy(G7[case["id"] + "_prompt"].astype(np.int64))[None]
+    noise = oracle.RecordedNoise(events_ragged(G7, case["id"]))
+    out, d = oracle.multi_speculative_sampling(prompt, oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd),
+                                               case["eos"], None, case["max_len"], width=case["width"],
+                                               strategy="iid", details=True, noise=noise, **case["kwargs"])
+    np.testing.assert_array_equal(out.numpy()[0], G7[case["id"] + "_out"])
+    assert d["acc_len"] == case["acc_len"]
+    assert abs(float(d["acc_rate"]) - case["acc_rate"]) < 1e-12
+    assert d["target_call_times"] == case["target_call_times"]
+    assert d["_rows_fed_draft"] == case["rows_fed_draft"] and d["_rows_fed_target"] == case["rows_fed_target"]
+    assert noise.exhausted()
+
+
+def test_multi_unsupported_strategies():
+    x = torch.zeros((1, 4), dtype=torch.int64)
+    with pytest.raises(NotImplementedError):
+        oracle.multi_speculative_sampling(x, None, None, 2, None, 4, strategy="beam")
+    with pytest.raises(RuntimeError):
+        oracle.multi_speculative_sampling(x, None, None, 2, None, 4, strategy="bogus")
+
+
 @pytest.mark.parametrize("case", G5_META["ar"], ids=[c["id"] for c in G5_META["ar"]])
 def test_autoregressive_trace_golden(case):
     cfg = load_config(case["cfg"])
