@@ -139,6 +139,33 @@ typedef struct {
 } sd_accept_item;
 int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, void *stream);
 
+/* Width-w acceptance of multi_speculative_sampling(strategy="iid") (speculative_sampling.py:1592-1640, SURVEY.md 8(f)
+ * rank 2): replica w drafted seq_w[L .. L+gamma); replicas are scanned in order, replica w accepts its i-th token iff
+ * r < min(1, p_w[L+i-1][j] / q_w[L+i-1][j]) (fp32 division; a NaN ratio rejects) and stops at its first reject; the
+ * replica with the longest accepted run wins (first one on ties; replica 0 when nothing was accepted) and the scan
+ * ends early at the first replica that accepts all gamma.  r: width*gamma device floats consumed strictly in that
+ * order (parity mode; n_uniform tells the caller how many the reference would have drawn), or NULL for device Philox
+ * (seed, draw_index + k).  `chosen` is filled like sd_accept_scan's result for the winning replica and feeds
+ * sd_multi_resample; p_at/q_at hold every replica's gathered probabilities ([w][i], 16 columns per replica) for the
+ * acc_rate statistic (:1592-1601).  `items` is a host array of width <= 16 entries. */
+typedef struct {
+    sd_accept_result chosen;
+    int32_t choice, n_uniform, width, gamma;
+    float p_at[256], q_at[256];
+} sd_multi_result;
+typedef struct {
+    const float *p_hist, *q_hist;     /* probability arenas of replica w, indexed by absolute position (row stride ld) */
+    const int32_t *seq;               /* replica w's token buffer */
+} sd_multi_item;
+int sd_accept_multi(const sd_multi_item *items, int width, long ld, int L, int gamma, const float *r,
+                    uint64_t philox_seed, uint64_t draw_index, sd_multi_result *out, void *stream);
+
+/* sd_resample with multi_speculative_sampling's fallback (speculative_sampling.py:1662-1668): when the residual
+ * sample raises, the token is drawn from p_n itself, not from max_fn(p_n).  Everything else as sd_resample. */
+int sd_multi_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
+                      const float *exp_noise, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res,
+                      void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder model + KV arena           reference sampling/models/modeling_{llama,opt}.py,
  *                                    sampling/kvcache_model.py:141-252 (forward), :359-436 (rollback)

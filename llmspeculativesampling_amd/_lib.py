@@ -35,6 +35,15 @@ class SdAcceptItem(C.Structure):
                 ("draw_resample", C.c_uint64), ("res", C.c_void_p), ("err_flags", C.c_void_p), ("n_err", C.c_int32)]
 
 
+class SdMultiResult(C.Structure):
+    _fields_ = [("chosen", SdAcceptResult), ("choice", C.c_int32), ("n_uniform", C.c_int32), ("width", C.c_int32),
+                ("gamma", C.c_int32), ("p_at", C.c_float * 256), ("q_at", C.c_float * 256)]
+
+
+class SdMultiItem(C.Structure):
+    _fields_ = [("p_hist", C.c_void_p), ("q_hist", C.c_void_p), ("seq", C.c_void_p)]
+
+
 class SdBatchItem(C.Structure):
     _fields_ = [("session", C.c_void_p), ("seq", C.c_void_p), ("pos0", C.c_int32), ("n_new", C.c_int32),
                 ("n_logits", C.c_int32)]
@@ -70,6 +79,8 @@ SYMBOLS = [
     ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_norm_batch", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, C.POINTER(SdNormRow), _I, _VP, _VP]),
     ("sd_accept_batch", _I, [C.POINTER(SdAcceptItem), _I, _L, _I, _I, _VP]),
+    ("sd_accept_multi", _I, [C.POINTER(SdMultiItem), _I, _L, _I, _I, _VP, _U64, _U64, _VP, _VP]),
+    ("sd_multi_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _VP, _U64, _U64, _VP, _VP]),
     ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),

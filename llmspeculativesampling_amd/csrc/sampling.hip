@@ -811,6 +811,7 @@ __global__ __launch_bounds__(64) void accept_scan_batch_kernel(AcceptTab t, long
     accept_scan_body(t.p_hist[b], t.q_hist[b], ld, t.seq[b], t.L[b], gamma, t.r[b], t.seed[b], t.draw_scan[b], t.res[b]);
 }
 
+template <bool PLAIN_FALLBACK = false>
 __device__ __forceinline__ void resample_body(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
                                               long ld, int V, int32_t *__restrict__ seq, int gamma,
                                               const float *__restrict__ noise, uint64_t seed, uint64_t draw,
@@ -838,8 +839,11 @@ __device__ __forceinline__ void resample_body(const float *__restrict__ p_hist, 
             part = 0.f;
             for (int i = threadIdx.x; i < V; i += NT) part += p[i] > 0.f ? p[i] : 0.f;
             const float denom2 = block_sum(part, red) + 1e-6f;
-            tok = sample_core(
-                V, [&](int i) { const float d = p[i]; return (d > 0.f ? d : 0.f) / denom2; }, E, S, &status);
+            if (PLAIN_FALLBACK)                                   // multi_speculative_sampling: sample(p_n) (:1666-1668)
+                tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status);
+            else
+                tok = sample_core(
+                    V, [&](int i) { const float d = p[i]; return (d > 0.f ? d : 0.f) / denom2; }, E, S, &status);
         }
     } else {
         tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status);   // bonus token from p_last (:2019)
@@ -863,6 +867,71 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
                                                      int32_t *__restrict__ seq_len,
                                                      const int *__restrict__ err_flags, int n_err) {
     resample_body(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, seq_len, err_flags, n_err);
+}
+
+__global__ __launch_bounds__(NT) void multi_resample_kernel(const float *__restrict__ p_hist,
+                                                           const float *__restrict__ q_hist, long ld, int V,
+                                                           int32_t *__restrict__ seq, int gamma,
+                                                           const float *__restrict__ noise, uint64_t seed,
+                                                           uint64_t draw, sd_accept_result *__restrict__ res) {
+    resample_body<true>(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, (int32_t *)nullptr,
+                        (const int *)nullptr, 0);
+}
+
+// Width-w acceptance (multi_speculative_sampling): gathers in parallel, the data-dependent scan on one thread.
+struct MultiTab {
+    const float *p_hist[16], *q_hist[16];
+    const int32_t *seq[16];
+};
+
+__global__ __launch_bounds__(256) void accept_multi_kernel(MultiTab t, int width, long ld, int L, int gamma,
+                                                          const float *__restrict__ r, uint64_t seed, uint64_t draw,
+                                                          sd_multi_result *__restrict__ out) {
+    __shared__ float sp[256], sq[256];
+    __shared__ int sj[256];
+    const int tid = threadIdx.x, w = tid >> 4, i = tid & 15;
+    float p = 0.f, q = 0.f;
+    int j = -1;
+    if (w < width && i < gamma) {
+        j = t.seq[w][L + i];
+        p = t.p_hist[w][(size_t)(L + i - 1) * ld + j];
+        q = t.q_hist[w][(size_t)(L + i - 1) * ld + j];
+    }
+    sp[tid] = p; sq[tid] = q; sj[tid] = j;
+    out->p_at[tid] = p;
+    out->q_at[tid] = q;
+    __syncthreads();
+    if (tid != 0) return;
+    int k = 0, max_l = 0, choice = 0, all = 0;
+    for (int ww = 0; ww < width; ++ww) {
+        int cur_l = 0, cur_all = 1;
+        for (int ii = 0; ii < gamma; ++ii) {
+            const float ri = r ? r[k] : philox_uniform(seed, draw + (uint64_t)k);
+            ++k;
+            const float ratio = __fdiv_rn(sp[ww * 16 + ii], sq[ww * 16 + ii]);
+            if (ratio >= 1.0f || ri < ratio) ++cur_l;             // r < min(1, p/q); NaN compares false -> reject
+            else { cur_all = 0; break; }
+        }
+        if (cur_l > max_l) {
+            max_l = cur_l;
+            choice = ww;
+            if (cur_all) { all = 1; break; }
+        }
+    }
+    out->choice = choice;
+    out->n_uniform = k;
+    out->width = width;
+    out->gamma = gamma;
+    sd_accept_result *c = &out->chosen;
+    c->n_accepted = max_l;
+    c->n = L + max_l - 1;
+    c->next_token = -1;
+    c->flags = all ? 4 : 0;
+    for (int ii = 0; ii < 16; ++ii) {
+        c->p_at[ii] = sp[choice * 16 + ii];
+        c->q_at[ii] = sq[choice * 16 + ii];
+        c->drafted[ii] = sj[choice * 16 + ii];
+    }
 }
 
 __global__ __launch_bounds__(NT) void resample_batch_kernel(AcceptTab t, long ld, int V, int gamma) {
@@ -1008,6 +1077,31 @@ int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, i
                             int n_err, hipStream_t st) {
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, gamma,
                        (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+extern "C" int sd_accept_multi(const sd_multi_item *items, int width, long ld, int L, int gamma, const float *r,
+                               uint64_t philox_seed, uint64_t draw_index, sd_multi_result *out, void *stream) {
+    SD_REQUIRE(items && out && width >= 1 && width <= 16, "sd_accept_multi: 1..16 replicas");
+    SD_REQUIRE(gamma >= 1 && gamma <= 16 && L >= 1, "sd_accept_multi: bad gamma / L");
+    MultiTab t = {};
+    for (int w = 0; w < width; ++w) {
+        SD_REQUIRE(items[w].p_hist && items[w].q_hist && items[w].seq, "sd_accept_multi: replica %d: bad arguments", w);
+        t.p_hist[w] = items[w].p_hist; t.q_hist[w] = items[w].q_hist; t.seq[w] = items[w].seq;
+    }
+    hipLaunchKernelGGL(accept_multi_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, t, width, ld, L, gamma, r,
+                       philox_seed, draw_index, out);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+extern "C" int sd_multi_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
+                                 const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
+                                 sd_accept_result *res, void *stream) {
+    SD_REQUIRE(p_hist && q_hist && seq && res && V > 0, "sd_multi_resample: bad arguments");
+    hipLaunchKernelGGL(multi_resample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p_hist, q_hist, ld, V, seq,
+                       gamma, exp_noise, philox_seed, draw_index, res);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }

@@ -50,6 +50,15 @@ class HostTorchNoise:
     def skip_exponential(self, V: int) -> None:
         torch.empty(V, dtype=torch.float32).exponential_(1, generator=self.gen)
 
+    def exponential_rows(self, rows: int, V: int) -> torch.Tensor:
+        """One draw of shape (rows, V): what torch.multinomial consumes for a (rows, V) input
+        (multi_speculative_sampling's width-w samples, kvcache_model.py:283 with multi > 1)."""
+        e = torch.empty((rows, V), dtype=torch.float32).exponential_(1, generator=self.gen)
+        return e.to(self.device, non_blocking=False)
+
+    def skip_exponential_rows(self, rows: int, V: int) -> None:
+        torch.empty((rows, V), dtype=torch.float32).exponential_(1, generator=self.gen)
+
     def uniforms(self, gamma: int, random_seed) -> Tuple[torch.Tensor, object]:
         """gamma uniforms as the reference would draw them if nothing were rejected, plus a token to
         re-align the generator once the accepted count is known."""
@@ -111,6 +120,15 @@ class ReplayNoise:
 
     def skip_exponential(self, V: int) -> None:
         self._take("exp")
+
+    def exponential_rows(self, rows: int, V: int) -> torch.Tensor:
+        e = torch.as_tensor(self._take("exp"), dtype=torch.float32)
+        assert e.numel() == rows * V, (tuple(e.shape), rows, V)
+        return e.reshape(rows, V).contiguous().to(self.device)
+
+    def skip_exponential_rows(self, rows: int, V: int) -> None:
+        e = torch.as_tensor(self._take("exp"))
+        assert e.numel() == rows * V
 
     def uniforms(self, gamma: int, random_seed):
         # the recording holds only the uniforms the reference actually consumed (it stops at the first

@@ -312,6 +312,113 @@ def test_speculative_live_host_rng_matches_reference_seed(hip):
         np.testing.assert_array_equal(out.cpu().numpy()[0], G5[cid + "_out"])
 
 
+G7_META, G7 = load("g7_multi")
+
+
+@pytest.mark.parametrize("case", G7_META, ids=[c["id"] for c in G7_META])
+def test_multi_speculative_trace_golden(hip, case):
+    """multi_speculative_sampling(strategy="iid") through the HIP engine, fed the noise the
+    reference consumed ((width, V) draws for the batched samples): its tokens, acc_len list, acc_rate and call counts."""
+    from golden_io import events_ragged
+    dcfg, dsd, tcfg, tsd = model_pair(case)
+    dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+    tm = dm if case["target_spec"][0] == "same" else hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.float32)
+    prompt = torch.from_numpy(G7[case["id"] + "_prompt"].astype(np.int64))[None].cuda()
+    nz = hip.noise.ReplayNoise(events_ragged(G7, case["id"]), "cuda")
+    out, d = hip.S.multi_speculative_sampling(prompt, dm, tm, case["eos"], None, case["max_len"], width=case["width"],
+                                              strategy="iid", details=True, rng=nz, **case["kwargs"])
+    np.testing.assert_array_equal(out.cpu().numpy()[0], G7[case["id"] + "_out"])
+    assert d["acc_len"] == case["acc_len"]
+    assert d["target_call_times"] == case["target_call_times"]
+    assert d["approx_call_times"] == case["approx_call_times"]
+    assert abs(float(d["acc_rate"]) - case["acc_rate"]) < 1e-4
+    assert nz.exhausted()
+    assert out.dtype == torch.int64 and out.shape[0] == 1 and out.is_cuda
+
+
+def test_multi_speculative_live_host_rng_and_device_rng(hip):
+    """Default rng="host" under the reference's outer seed reproduces its run; rng="device" (Philox) is deterministic
+    per seed, respects max_len and equals the oracle fed the same models in distribution only (not checked here)."""
+    for cid in ("m_llama_corr", "m_llama_seeded", "m_opt_post_pair"):
+        case = [c for c in G7_META if c["id"] == cid][0]
+        dcfg, dsd, tcfg, tsd = model_pair(case)
+        dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+        tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.float32)
+        prompt = torch.from_numpy(G7[cid + "_prompt"].astype(np.int64))[None].cuda()
+        torch.manual_seed(case["outer_seed"])
+        out = hip.S.multi_speculative_sampling(prompt, dm, tm, case["eos"], None, case["max_len"], width=case["width"],
+                                               strategy="iid", **case["kwargs"])
+        np.testing.assert_array_equal(out.cpu().numpy()[0], G7[cid + "_out"])
+        runs = [hip.S.multi_speculative_sampling(prompt, dm, tm, case["eos"], None, case["max_len"],
+                                                 width=case["width"], strategy="iid",
+                                                 rng=hip.noise.DeviceNoise(5), details=True, **case["kwargs"])
+                for _ in range(2)]
+        assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1]["acc_len"] == runs[1][1]["acc_len"]
+        g = case["kwargs"].get("gamma", 4)
+        assert case["L"] + case["max_len"] <= runs[0][0].shape[1] <= case["L"] + case["max_len"] + g
+        assert torch.equal(runs[0][0][:, :case["L"]], prompt)
+    with pytest.raises(NotImplementedError):
+        hip.S.multi_speculative_sampling(prompt, dm, tm, 2, None, 4)                    # default strategy "beam"
+    with pytest.raises(RuntimeError):
+        hip.S.multi_speculative_sampling(prompt, dm, tm, 2, None, 4, strategy="bogus")
+
+
+def test_accept_multi_kernel_vs_reference_rule(hip):
+    """sd_accept_multi on synthetic rows against a literal restatement of the reference's replica scan
+    (speculative_sampling.py:1611-1638): choice, run length, early stop on the first all-accepting replica, uniforms
+    consumed, NaN / zero-q ratios."""
+    import ctypes as C
+    L_ = hip.L
+    rng = np.random.default_rng(3)
+    V, S, Lp = 64, 24, 5
+    for trial in range(40):
+        W, gamma = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+        P = rng.random((W, S, V)).astype(np.float32)
+        Q = rng.random((W, S, V)).astype(np.float32)
+        if trial % 3 == 0:
+            Q = P.copy()                                   # ratio exactly 1 -> always accepted
+        if trial % 5 == 1:
+            Q[:, Lp:, :] *= 4.0                            # low ratios -> early rejects
+        seq = rng.integers(0, V, size=(W, S)).astype(np.int32)
+        if trial % 7 == 2:
+            P[0, Lp - 1, seq[0, Lp]] = 0.0
+            Q[0, Lp - 1, seq[0, Lp]] = 0.0                 # 0/0 = NaN -> reject
+        r = rng.random(W * gamma).astype(np.float32)
+        # reference rule
+        k = 0
+        max_l, choice, allacc = 0, 0, False
+        for w in range(W):
+            cur_l, cur_all = 0, True
+            for i in range(gamma):
+                ri = torch.tensor([r[k]])
+                k += 1
+                j = int(seq[w, Lp + i])
+                ratio = torch.tensor(P[w, Lp + i - 1, j]) / torch.tensor(Q[w, Lp + i - 1, j])
+                if ri < torch.min(torch.tensor([1]), ratio):
+                    cur_l += 1
+                else:
+                    cur_all = False
+                    break
+            if cur_l > max_l:
+                max_l, choice = cur_l, w
+                if cur_all:
+                    allacc = True
+                    break
+        Pd, Qd = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
+        sd_, rd = torch.from_numpy(seq).cuda(), torch.from_numpy(r).cuda()
+        items = (L_.SdMultiItem * W)()
+        for w in range(W):
+            items[w].p_hist, items[w].q_hist, items[w].seq = Pd[w].data_ptr(), Qd[w].data_ptr(), sd_[w].data_ptr()
+        res = torch.zeros(C.sizeof(L_.SdMultiResult), dtype=torch.uint8, device="cuda")
+        L_.check(L_.lib.sd_accept_multi(items, W, V, Lp, gamma, rd.data_ptr(), 0, 0, res.data_ptr(), _st()),
+                 "sd_accept_multi")
+        out = L_.SdMultiResult.from_buffer_copy(res.cpu().numpy().tobytes())
+        assert (out.choice, out.chosen.n_accepted, out.n_uniform, bool(out.chosen.flags & 4)) == \
+            (choice, max_l, k, allacc), trial
+        assert out.chosen.n == Lp + max_l - 1
+        assert [out.chosen.drafted[i] for i in range(gamma)] == [int(x) for x in seq[choice, Lp:Lp + gamma]]
+
+
 @pytest.mark.parametrize("case", G5_META["ar"], ids=[c["id"] for c in G5_META["ar"]])
 def test_autoregressive_trace_golden(hip, case):
     cfg = load_config(case["cfg"])

@@ -32,6 +32,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from llmspeculativesampling_amd import _lib
     assert C.sizeof(_lib.SdAcceptResult) == 16 + 64 + 64 + 64
+    assert C.sizeof(_lib.SdMultiResult) == 208 + 16 + 2 * 1024 and C.sizeof(_lib.SdMultiItem) == 24
     assert C.sizeof(_lib.SdModelConfig) == 15 * 4
     assert C.sizeof(_lib.SdModelWeights) == 21 * 8
 
