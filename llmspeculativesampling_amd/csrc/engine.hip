@@ -185,12 +185,13 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     const int wide = std::max(c.hidden, ed);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t trows = align_up(rows, 16);                     // GEMM operands live in 16-row tiles (xoff)
     p.x = take((size_t)rows * c.hidden * es);
-    p.h = take((size_t)rows * wide * es);
+    p.h = take(trows * wide * es);
     p.q = take((size_t)rows * c.hidden * es);
-    p.attn = take((size_t)rows * c.hidden * es);
-    p.act = take((size_t)rows * c.inter * es);
-    p.e = take((size_t)rows * ed * es);
+    p.attn = take(trows * c.hidden * es);
+    p.act = take(trows * c.inter * es);
+    p.e = take(trows * ed * es);
     p.apart = take((size_t)64 * c.n_heads * 8 * (c.head_dim + 2) * sizeof(float));
     size_t pf = 0;
     pf = std::max(pf, gemm_part_floats(c, qkv_cols(c), c.hidden, rows));
@@ -443,13 +444,13 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     if (llama || ED == H) {
         ProfScope ps(s, PC_EMBED, st);
         hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, H,
-                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x);
+                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, 0);
         SD_LAUNCH_CHECK();
     } else {
         {
             ProfScope ps(s, PC_EMBED, st);
             hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, ED,
-                               (const T *)nullptr, 0, eb);
+                               (const T *)nullptr, 0, eb, 1);
             SD_LAUNCH_CHECK();
         }
         if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
@@ -465,7 +466,9 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                            (const T *)m->n1b[0], c.norm_eps, norm_kind, h);
         SD_LAUNCH_CHECK();
     } else {
-        SD_HIP_CHECK(hipMemcpyAsync(h, x, (size_t)n_new * H * sizeof(T), hipMemcpyDeviceToDevice, st));
+        ProfScope ps(s, PC_NORM, st);
+        hipLaunchKernelGGL((to_operand_kernel<T>), dim3(n_new), dim3(256), 0, st, (const T *)x, H, h);
+        SD_LAUNCH_CHECK();
     }
 
     for (int l = 0; l < L; ++l) {
@@ -671,6 +674,7 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, i
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
     GemmEpi e = {};
+    e.x_rowmajor = 1;
     if (dispatch_gemm_bf16<EPI_PART>(w_packed, x, part, M, Mpad, N, K, S, ksp, e, st) != SD_OK) return SD_ERR_INVALID;
     SD_LAUNCH_CHECK();
     if (out) {

@@ -27,6 +27,19 @@ struct RowTab {
     int grp_row0[SD_MAX_GROUPS], grp_n[SD_MAX_GROUPS], grp_pos[SD_MAX_GROUPS], grp_stream[SD_MAX_GROUPS];
 };
 
+// Activation operands of the bf16 GEMMs (normalised rows, attention output, MLP activation, OPT projections) are kept
+// in the MFMA B-operand tile layout [M/16][K/32][64 lanes][8]: lane 16*((k/8)%4) + m%16 of tile (m/16, k/32) holds
+// X[m][k..k+8).  A wave's fragment load is then one contiguous 1 KiB read instead of 16 row segments 2*K bytes apart
+// (measured on the 13b shapes, tools/gemm_bench.py: gate/up at 16 rows 59.8 -> 49.0 us, at 64 rows 74 -> 63 us).
+// Producers write through xoff<T>(); fp32 models (gemm_f32_simple) keep plain rows.
+template <typename T>
+__device__ __forceinline__ size_t xoff(int m, int k, int K) {
+    if constexpr (sizeof(T) == 2)
+        return ((size_t)(m >> 4) * (K >> 5) + (k >> 5)) * 512 + ((((k >> 3) & 3) << 4) + (m & 15)) * 8 + (k & 7);
+    else
+        return (size_t)m * K + k;
+}
+
 enum { NORM_RMS = 0, NORM_LN = 1 };
 enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual feeds the next GEMM / replaces x / no norm
 
@@ -47,6 +60,7 @@ struct GemmEpi {
     int Hq, Hkv, D, layer;    // QKV: K / V rows go to tab.kv_base[stream] + layer offset, at position tab.row_pos[m]
     float q_scale;
     int use_xmap;             // lm_head: activation row m is tab.xmap[m] of X
+    int x_rowmajor;           // X is plain [M][K] rows (the public sd_gemm_bf16 entry) instead of the tile layout
     RowTab tab;
 };
 
@@ -81,8 +95,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         const int m = t * 16 + mrow;
         mv[t] = m < M;
         const int msrc = mv[t] ? (e.use_xmap ? (int)e.tab.xmap[m] : m) : 0;
-        xp[t] = X + (size_t)msrc * K + (size_t)ks0 * 32 + kq;
+        xp[t] = e.x_rowmajor ? X + (size_t)msrc * K + (size_t)ks0 * 32 + kq
+                             : X + ((size_t)(msrc >> 4) * KS + ks0) * 512 + ((lane >> 4) * 16 + (msrc & 15)) * 8;
     }
+    const int xstep = e.x_rowmajor ? 32 : 512;                    // elements from one k-tile's fragment to the next
     f32x4 acc[NTW][MT];
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-                x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * 32) : u32x4{0u, 0u, 0u, 0u};
+                x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * xstep) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
@@ -113,7 +129,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int j = 0; j < NTW; ++j) wp[j] += (size_t)UNROLL * 64;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xp[t] += UNROLL * 32;
+        for (int t = 0; t < MT; ++t) xp[t] += UNROLL * xstep;
     }
     for (; ks < ks1; ++ks) {
         u32x4 w[NTW];
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             for (int j = 0; j < NTW; ++j)
                 acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]),
                                                                    __builtin_bit_cast(bf16x8, x), acc[j][t], 0, 0, 0);
-            xp[t] += 32;
+            xp[t] += xstep;
         }
     }
 #pragma unroll
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
                     const float gj = rnd<bf16_t>(g[q]), uj = rnd<bf16_t>(u[q]);
                     a[q] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
                 }
-                store4(e.out + (size_t)m * e.n_out + nt * 8 + (l >> 4) * 4, a[0], a[1], a[2], a[3]);
+                store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
                     const float f = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
                     a[q] = f > 0.f ? f : 0.f;
                 }
-                store4(e.out + (size_t)m * e.n_out + col, a[0], a[1], a[2], a[3]);
+                store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else {
@@ -304,7 +320,7 @@ __device__ __forceinline__ f32x4 reduce_part4(const float *__restrict__ part, in
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, const T *__restrict__ pos_table,
-                             int pos_off, T *__restrict__ out) {
+                             int pos_off, T *__restrict__ out, int tiled) {
     const int row = blockIdx.x;
     const int pos = tab.row_pos[row];
     const int tok = tab.tok_base[tab.row_stream[row]][pos];
@@ -313,8 +329,15 @@ __global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, c
     for (int i = threadIdx.x; i < dim; i += blockDim.x) {
         float v = to_f(src[i]);
         if (ps) v = rnd<T>(v + to_f(ps[i]));
-        out[(size_t)row * dim + i] = from_f<T>(v);
+        out[tiled ? xoff<T>(row, i, dim) : (size_t)row * dim + i] = from_f<T>(v);   // tiled: feeds project_in
     }
+}
+
+// plain rows -> GEMM operand layout (OPT post-LN: the first layer's QKV input is x itself)
+template <typename T>
+__global__ void to_operand_kernel(const T *__restrict__ x, int H, T *__restrict__ h) {
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) h[xoff<T>(row, i, H)] = x[(size_t)row * H + i];
 }
 
 // x = rnd(rnd(sum part) + pos)   (OPT project_in output plus learned positions, modeling_opt.py:669-672)
@@ -338,7 +361,7 @@ __global__ void reduce_addpos_kernel(const float *__restrict__ part, int S, size
 template <typename T>
 __device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, const T *__restrict__ w,
                                          const T *__restrict__ b, float eps, int kind, float *red,
-                                         T *__restrict__ dst0, T *__restrict__ dst1) {
+                                         T *__restrict__ hbase, int row) {
     float a = 0.f, a2 = 0.f;
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         const float v = xs[i];
@@ -350,8 +373,7 @@ __device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, co
         const float r = rsqrtf(var + eps);
         for (int i = threadIdx.x; i < H; i += blockDim.x) {
             const float y = rnd<T>(to_f(w[i]) * rnd<T>(xs[i] * r));
-            if (dst0) dst0[i] = from_f<T>(y);
-            if (dst1) dst1[i] = from_f<T>(y);
+            hbase[xoff<T>(row, i, H)] = from_f<T>(y);
         }
     } else {
         const float mean = block_sum(a, red) / (float)H;
@@ -364,8 +386,7 @@ __device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, co
         const float r = 1.0f / sqrtf(var + eps);
         for (int i = threadIdx.x; i < H; i += blockDim.x) {
             const float y = rnd<T>((xs[i] - mean) * r * to_f(w[i]) + to_f(b[i]));
-            if (dst0) dst0[i] = from_f<T>(y);
-            if (dst1) dst1[i] = from_f<T>(y);
+            hbase[xoff<T>(row, i, H)] = from_f<T>(y);
         }
     }
 }
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const T *__restrict__ x, int 
     const int row = blockIdx.x;
     for (int i = threadIdx.x; i < H; i += blockDim.x) xs[i] = to_f(x[(size_t)row * H + i]);
     __syncthreads();
-    norm_row<T>(xs, H, w, b, eps, kind, red, h + (size_t)row * H, nullptr);
+    norm_row<T>(xs, H, w, b, eps, kind, red, h, row);
 }
 
 // x' = rnd(x + rnd(sum part + bias)); then per mode: PRE: x <- x', h <- norm(x');  POST: x,h <- LN(x');
@@ -412,8 +433,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
                                                             float eps, int kind, int mode, T *__restrict__ h) {
     __shared__ float red[32];
     const int row = blockIdx.x;
-    T *xr = x + (size_t)row * H;
-    T *hr = h + (size_t)row * H;
+    T *xr = x + (size_t)row * H;                                  // residual stream: plain rows; h: GEMM operand layout
     float v[RN_RG][4], wv[RN_RG][4], bv[RN_RG][4];
     bool on[RN_RG];
     f32x4 y4[RN_RG];
@@ -446,7 +466,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
             a2 += v[g][j] * v[g][j];
         }
         if (mode != RES_POST) store4t<T>(xr + i, v[g]);
-        if (mode == RES_NONE) store4t<T>(hr + i, v[g]);
+        if (mode == RES_NONE) store4t<T>(h + xoff<T>(row, i, H), v[g]);
     }
     if (mode == RES_NONE) return;
     float mean = 0.f, r;
@@ -471,7 +491,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
         for (int j = 0; j < 4; ++j)
             o[j] = kind == NORM_RMS ? rnd<T>(wv[g][j] * rnd<T>(v[g][j] * r))
                                     : rnd<T>((v[g][j] - mean) * r * wv[g][j] + bv[g][j]);
-        store4t<T>(hr + i, o);
+        store4t<T>(h + xoff<T>(row, i, H), o);
         if (mode == RES_POST) store4t<T>(xr + i, o);
     }
 }
@@ -777,7 +797,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         float a = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
-        out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a);
+        out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(a);
     }
 }
 
@@ -800,7 +820,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
             L += r[D + 1] * w;
             a += r[d] * w;
         }
-        out[(size_t)(r0 + t) * Hq * D + head * D + d] = from_f<T>(a / L);
+        out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(a / L);
     }
 }
 
@@ -823,7 +843,7 @@ __global__ void act_kernel(const float *__restrict__ part, int S, size_t stride_
         const float f = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + c, bias, c);
         a = f > 0.f ? f : 0.f;
     }
-    act[(size_t)row * I + c] = from_f<T>(a);
+    act[xoff<T>(row, c, I)] = from_f<T>(a);
 }
 
 // Generic split-K reduce into T rows (OPT project_out) or fp32 logits.
@@ -833,7 +853,7 @@ __global__ void reduce_rows_kernel(const float *__restrict__ part, int S, size_t
     const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
-    out[(size_t)row * N + c] = from_f<T>(reduce_part<T>(part, S, stride_s, (size_t)row * N + c, nullptr, c));
+    out[xoff<T>(row, c, N)] = from_f<T>(reduce_part<T>(part, S, stride_s, (size_t)row * N + c, nullptr, c));
 }
 
 template <typename T>

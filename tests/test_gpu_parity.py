@@ -4,6 +4,7 @@ Run with ``pytest -m gpu`` on an MI355X.  Bars: token ids bit-exact; probabiliti
 absolute with an identical support set; fp32 logits within 1e-3 (north_star); bf16 logits within
 0.25 of the reference's bf16 forward (same bar the oracle is held to).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -787,3 +788,21 @@ def test_host_rng_autoregressive_matches_reference_seed(hip):
     torch.manual_seed(77)
     out = hip.S.autoregressive_sampling(prompt, m, case["N"], case["eos"], **case["kwargs"])
     np.testing.assert_array_equal(out.cpu().numpy()[0], G5[case["id"] + "_out"])
+
+
+def test_evaluation_driver_runs_offline(tmp_path):
+    """tools/evaluation.py (the reference driver's three loops) end to end on tiny models and
+    synthetic prompts: every loop prints its result lines in the reference's wording."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = tmp_path / "log.txt"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluation.py"), "--approx_model_name",
+                        "tiny-llama-draft", "--target_model_name", "tiny-llama-target", "--n-prompts", "40",
+                        "--max_tokens", "8", "--repeats", "1", "--dtype", "float32", "--seed", "7", "--log_file",
+                        str(log)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = log.read_text()
+    assert "large model total time" in text and "google speculative decoding (with KVCache) total time" in text
+    assert "iid multi-draft speculative decoding (gamma 4, width 2) total time" in text
+    assert text.count("average accepted len") == 2 and text.count("power/token:") == 3

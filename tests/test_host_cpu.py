@@ -151,3 +151,36 @@ def test_gather_streams_world_size_2_gloo(n_streams):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in got)
     assert all(t == 2.0 for _, _, t in got)
+
+
+# --------------------------------------------------------------------------- evaluation-driver host pieces (8(f) rank 3)
+def test_harness_chatalpaca_reader_and_power_sum(tmp_path):
+    """read_chatalpaca: one prompt per assistant turn with the cumulative, newline-joined history
+    (reference evaluation.py:347-364); total_power: samples strictly inside (t1, t2), first one dropped, cut-off
+    lines skipped (evaluation.py:135-152)."""
+    import json
+    from llmspeculativesampling_amd import harness
+    p = tmp_path / "chat.json"
+    convs = [{"conversations": [{"from": "human", "value": "hi"}, {"from": "gpt", "value": "hello"},
+                                {"from": "human", "value": "more"}, {"from": "gpt", "value": "sure"}]},
+             {"conversations": [{"from": "human", "value": "a"}, {"from": "human", "value": "b"},
+                                {"from": "gpt", "value": "c"}]}]
+    p.write_text("\n".join(json.dumps(c) for c in convs) + "\n")
+    prompts, answers = harness.read_chatalpaca(str(p))
+    assert prompts == ["hi\n", "hi\nhello\nmore\n", "a\nb\n"]
+    assert answers == ["hello", "sure", "c"]
+    lines = ["9.0 100.0", "10.5 200.0", "11.5 300.0", "12.5 400.0", "13.5", "garbage x", "20.0 500.0"]
+    assert harness.total_power(lines, 10.0, 13.0) == 700.0          # 200 is the dropped first sample
+    assert harness.total_power([], 0.0, 1.0) == 0.0
+    tok = harness.ByteTokenizer(512)
+    ids = tok.encode("héllo\n", return_tensors="pt")
+    assert ids.shape[0] == 1 and int(ids[0, 0]) == 1 and tok.decode(ids[0].tolist()) == "héllo\n"
+    ds = harness.synthetic_prompts(5, 1000)
+    assert all(d.shape[0] == 1 and 32 <= d.shape[1] <= 512 and int(d.min()) >= 3 and int(d.max()) < 1000 for d in ds)
+    assert [d.shape[1] for d in ds] == [d.shape[1] for d in harness.synthetic_prompts(5, 1000)]
+    agg = dict(approx_time=2e9, target_time=3e9, other_time=1e9, acc_len_sum=30.0, acc_rate=[0.5, 0.7],
+               target_call_times=10, approx_call_times=10)
+    out = harness.speculative_log_lines("google speculative decoding (with KVCache)", int(6e9), 40, agg, [-1.0, -3.0], 90.0)
+    assert "total time 6.0 s, total tokens 40, average time 0.15 s/token" in out[0]
+    assert out[2].startswith("average accepted len 3.0, target call times 10, acc rate 0.6")
+    assert out[-1] == "power/token: 2.25"
