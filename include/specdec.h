@@ -222,12 +222,18 @@ int sd_model_destroy(sd_model *m);
  * GEMM kernels read: 1 KiB tiles [N/16][K/32][lane 0..63][8 bf16], lane = 16*(k/8 % 4) + n % 16. */
 int sd_pack_weight_bf16(const void *w_rowmajor, void *w_packed, int N, int K, void *stream);
 
+/* Row-major bf16 activations [M][K] (K % 32 == 0) -> the GEMM operand layout the engine keeps them in between
+ * kernels: 16-row tiles [ceil(M/16)][K/32][lane 0..63][8 bf16], lane = 16*(k/8 % 4) + m % 16, so that a wave's MFMA
+ * fragment is one contiguous 1 KiB read.  x_tiled must hold roundup(M,16) * K elements. */
+int sd_pack_activation_bf16(const void *x_rowmajor, void *x_tiled, int M, int K, void *stream);
+
 /* The weight-streaming GEMM on its own (unit tests, kernel-level roofline runs):
  * part[s][m][n] = sum over k-slice s of x[m][k] * W[n][k] for a tile-packed bf16 W, then (if out != NULL)
- * out[m][n] = sum_s part[s][m][n] in fp32.  M <= 64.  part must hold splits * roundup(M,16) * N floats;
- * the split count the policy chose comes back in *splits_out. */
-int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, int K, float *part, size_t part_floats,
-                 float *out, int *splits_out, void *stream);
+ * out[m][n] = sum_s part[s][m][n] in fp32.  M <= 64.  x: plain rows (x_tiled == 0) or sd_pack_activation_bf16's
+ * layout (x_tiled != 0, what the forward uses).  part must hold splits * roundup(M,16) * N floats; the split count the
+ * policy chose comes back in *splits_out. */
+int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, int M, int N, int K, float *part,
+                 size_t part_floats, float *out, int *splits_out, void *stream);
 
 /* A session = one KV arena + scratch for one sequence (one KVCacheModel of the reference).
  * kv_arena: [n_layers][2][n_kv_heads][max_seq][head_dim] in `dtype`, caller-allocated.

@@ -88,7 +88,8 @@ SYMBOLS = [
     ("sd_model_create", _I, [C.POINTER(SdModelConfig), C.POINTER(SdModelWeights), C.POINTER(_VP)]),
     ("sd_model_destroy", _I, [_VP]),
     ("sd_pack_weight_bf16", _I, [_VP, _VP, _I, _I, _VP]),
-    ("sd_gemm_bf16", _I, [_VP, _VP, _I, _I, _I, _VP, C.c_size_t, _VP, C.POINTER(C.c_int), _VP]),
+    ("sd_pack_activation_bf16", _I, [_VP, _VP, _I, _I, _VP]),
+    ("sd_gemm_bf16", _I, [_VP, _VP, _I, _I, _I, _I, _VP, C.c_size_t, _VP, C.POINTER(C.c_int), _VP]),
     ("sd_session_kv_bytes", C.c_size_t, [_VP, _I]),
     ("sd_session_scratch_bytes", C.c_size_t, [_VP, _I]),
     ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),

@@ -108,10 +108,14 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 static int gemm_ntw(int N, int M) {
     if (M <= 16) return 1;
     const int ntl = N / 16;
+    // n-tiles per wave: more of them amortise the activation fragment loads, fewer give more workgroups (the fused
+    // epilogues run with SB = 1).  Whole 13b forward, tools/forward_rows_bench.py: 20 rows 6.33 ms with 4 tiles,
+    // 6.04 with 2; 40 rows 7.16 / 6.96; 64 rows 7.77 / 8.94.  8 tiles: register pressure, slower everywhere.
     const char *env = getenv("SD_GEMM_NTW");
-    const int want = env ? atoi(env) : 4;      // 8 tiles per wave measured slower (register pressure, too few workgroups)
+    const int want = env ? atoi(env) : (M <= 48 ? 2 : 4);
     if (want >= 8 && ntl % 8 == 0) return 8;
     if (want >= 4 && ntl % 4 == 0) return 4;
+    if (want >= 2 && ntl % 2 == 0) return 2;
     return 1;
 }
 
@@ -158,7 +162,8 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
 static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
     if (c.dtype != SD_BF16) return (size_t)rows * N;
     size_t best = 0;
-    for (int m : {1, rows}) {
+    for (int m : {1, 16, 17, 32, 33, 48, 49, rows}) {            // every (m-tile count, tiles-per-wave) class the policy has
+        if (m > rows) continue;
         int S, ksp;
         gemm_split(N, K, m, &S, &ksp);
         best = std::max(best, (size_t)S * align_up(m, 16) * N);
@@ -329,12 +334,15 @@ static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, 
     const int ntw = gemm_ntw(N, M);
     if (MT == 1) launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
     else if (MT == 2) { if (ntw >= 4) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<2, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<2, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else if (MT == 3) { if (ntw == 8) launch_gemm_bf16<3, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else if (ntw == 4) launch_gemm_bf16<3, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<3, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<3, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else if (MT == 4) { if (ntw == 8) launch_gemm_bf16<4, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else if (ntw == 4) launch_gemm_bf16<4, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<4, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
                         else launch_gemm_bf16<4, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else { sd_set_error("gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
     return SD_OK;
@@ -664,7 +672,15 @@ __global__ void reduce_f32_kernel(const float *__restrict__ part, int S, size_t 
     out[i] = reduce_part<float>(part, S, stride_s, (size_t)i, nullptr, 0);
 }
 
-extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, int K, float *part,
+extern "C" int sd_pack_activation_bf16(const void *x_rowmajor, void *x_tiled, int M, int K, void *stream) {
+    SD_REQUIRE(x_rowmajor && x_tiled && M >= 1 && K >= 32 && K % 32 == 0, "sd_pack_activation_bf16: need M>=1, K%%32==0");
+    hipLaunchKernelGGL((to_operand_kernel<bf16_t>), dim3(M), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)x_rowmajor, K, (bf16_t *)x_tiled);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, int M, int N, int K, float *part,
                             size_t part_floats, float *out, int *splits_out, void *stream) {
     SD_REQUIRE(w_packed && x && part, "sd_gemm_bf16: null argument");
     SD_REQUIRE(M >= 1 && M <= 64 && N % 16 == 0 && K % 32 == 0, "sd_gemm_bf16: need 1<=M<=64, N%%16==0, K%%32==0");
@@ -674,7 +690,7 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int M, int N, i
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
     GemmEpi e = {};
-    e.x_rowmajor = 1;
+    e.x_rowmajor = x_tiled ? 0 : 1;
     if (dispatch_gemm_bf16<EPI_PART>(w_packed, x, part, M, Mpad, N, K, S, ksp, e, st) != SD_OK) return SD_ERR_INVALID;
     SD_LAUNCH_CHECK();
     if (out) {

@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
     // One workgroup = NTW consecutive 16-column n-tiles x one k-slab; its 4 waves take a quarter of the slab each
     // (every activation fragment a wave loads is reused for NTW weight tiles) and fold their accumulators through
     // LDS, so the number of partial slabs in HBM is SB, not 4*SB.  NTW = 1 for decode (M <= 16), 4 for prefill rows.
-    constexpr int NTH = NTW > 4 ? 4 : NTW;                        // n-tiles folded through LDS per pass
-    __shared__ f32x4 red[4][NTH][MT][64];
+    constexpr int NP = NTW * MT;                                  // accumulator tiles per wave
+    constexpr int PT = NP % 4 == 0 ? 4 : (NP % 2 == 0 ? 2 : 1);    // of which PT go through the LDS fold per step
+    __shared__ f32x4 red[4][PT][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int NTG = (N >> 4) / NTW, KS = K >> 5;
     const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
@@ -145,92 +146,93 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             xp[t] += xstep;
         }
     }
+    // Fold the 4 waves' accumulators through LDS, PT tiles at a time (a fold buffer for all NTW*MT tiles at once would be
+    // 64 KiB at 4x4 and cap the kernel at two workgroups per CU), each step followed by its share of the epilogue.
 #pragma unroll
-    for (int half = 0; half < NTW / NTH; ++half) {
-    if (half) __syncthreads();
+    for (int fs = 0; fs < NP / PT; ++fs) {
+        if (fs) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NTH; ++j)
+        for (int pp = 0; pp < PT; ++pp) red[wv][pp][lane] = acc[(fs * PT + pp) / MT][(fs * PT + pp) % MT];
+        __syncthreads();
+        auto folded = [&](int pp, int l) -> f32x4 {
+            return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
+        };
+        if constexpr (EPI == EPI_PART) {
+            if (threadIdx.x < PT * 64) {
+                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+                const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
+                if (m < M)
+                    *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(pp, l);
+            }
+        } else if constexpr (EPI == EPI_ACT_SILU) {
+            // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
+            if (threadIdx.x < PT * 32) {
+                const int pp = threadIdx.x >> 5, l = threadIdx.x & 31, q = fs * PT + pp;
+                const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
+                if (m < M) {
+                    const f32x4 g = folded(pp, l), u = folded(pp, l + 32);
+                    float a[4];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) red[wv][j][t][lane] = acc[half * NTH + j][t];
-    __syncthreads();
-    auto folded = [&](int j, int t, int l) -> f32x4 {
-        return (red[0][j][t][l] + red[1][j][t][l]) + (red[2][j][t][l] + red[3][j][t][l]);
-    };
-    if constexpr (EPI == EPI_PART) {
-        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
-            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), nt = ntg * NTW + half * NTH + j;
-            if (m < M)
-                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(j, t, l);
-        }
-    } else if constexpr (EPI == EPI_ACT_SILU) {
-        // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
-        for (int idx = threadIdx.x; idx < NTH * MT * 32; idx += 256) {
-            const int j = idx / (MT * 32), r2 = idx - j * (MT * 32), t = r2 >> 5, l = r2 & 31;
-            const int m = t * 16 + (l & 15), nt = ntg * NTW + half * NTH + j;
-            if (m < M) {
-                const f32x4 g = folded(j, t, l), u = folded(j, t, l + 32);
-                float a[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float gj = rnd<bf16_t>(g[q]), uj = rnd<bf16_t>(u[q]);
-                    a[q] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                    for (int c = 0; c < 4; ++c) {
+                        const float gj = rnd<bf16_t>(g[c]), uj = rnd<bf16_t>(u[c]);
+                        a[c] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                    }
+                    store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
                 }
-                store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
+            }
+        } else if constexpr (EPI == EPI_ACT_RELU) {
+            if (threadIdx.x < PT * 64) {
+                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+                const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
+                if (m < M) {
+                    const f32x4 r = folded(pp, l);
+                    float a[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float f = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                        a[c] = f > 0.f ? f : 0.f;
+                    }
+                    store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
+                }
+            }
+        } else {
+            // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
+            // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
+            const int hd = e.D >> 1;
+            if (threadIdx.x < PT * 64) {
+                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+                const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
+                if (m < M) {
+                    const f32x4 r = folded(pp, l);
+                    const int head = col / e.D, within = col - head * e.D;
+                    const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
+                    const int strm = e.tab.row_stream[m], pos = e.tab.row_pos[m], mseq = e.tab.max_seq[strm];
+                    bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
+                    bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
+                                       : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
+                                               : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
+                    float x[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                    if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int d = (within >> 1) + pr;
+                            const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
+                            const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
+                            dst[d] = (bf16_t)(rnd<bf16_t>(x0 * cs) + rnd<bf16_t>(-x1 * sn));
+                            dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * cs) + rnd<bf16_t>(x0 * sn));
+                        }
+                    } else {
+                        if (EPI == EPI_QKV_PLAIN && is_q) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(x[c] * e.q_scale);
+                        }
+                        store4(dst + within, x[0], x[1], x[2], x[3]);
+                    }
+                }
             }
         }
-    } else if constexpr (EPI == EPI_ACT_RELU) {
-        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
-            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), col = (ntg * NTW + half * NTH + j) * 16 + (l >> 4) * 4;
-            if (m < M) {
-                const f32x4 r = folded(j, t, l);
-                float a[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float f = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
-                    a[q] = f > 0.f ? f : 0.f;
-                }
-                store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
-            }
-        }
-    } else {
-        // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
-        // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
-        const int hd = e.D >> 1;
-        for (int idx = threadIdx.x; idx < NTH * MT * 64; idx += 256) {
-            const int j = idx / (MT * 64), r2 = idx - j * (MT * 64), t = r2 >> 6, l = r2 & 63;
-            const int m = t * 16 + (l & 15), col = (ntg * NTW + half * NTH + j) * 16 + (l >> 4) * 4;
-            if (m >= M) continue;
-            const f32x4 r = folded(j, t, l);
-            const int head = col / e.D, within = col - head * e.D;
-            const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
-            const int strm = e.tab.row_stream[m], pos = e.tab.row_pos[m], mseq = e.tab.max_seq[strm];
-            bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
-            bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
-                               : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
-                                       : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
-            float x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = rnd<bf16_t>(r[q] + (e.bias ? to_f(e.bias[col + q]) : 0.f));
-            if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int d = (within >> 1) + pr;
-                    const float c = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
-                    const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
-                    dst[d] = (bf16_t)(rnd<bf16_t>(x0 * c) + rnd<bf16_t>(-x1 * sn));
-                    dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * c) + rnd<bf16_t>(x0 * sn));
-                }
-            } else {
-                if (EPI == EPI_QKV_PLAIN && is_q) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = rnd<bf16_t>(x[q] * e.q_scale);
-                }
-                store4(dst + within, x[0], x[1], x[2], x[3]);
-            }
-        }
-    }
     }
 }
 

@@ -481,11 +481,22 @@ def test_gemm_bf16_stream_vs_fp32_reference(hip, N, K):
         x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
         S = C.c_int(0)
-        hip.L.check(hip.lib.sd_gemm_bf16(Wp.data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(),
+        hip.L.check(hip.lib.sd_gemm_bf16(Wp.data_ptr(), x.data_ptr(), 0, M, N, K, part.data_ptr(), part.numel(),
                                          out.data_ptr(), C.byref(S), _st()))
         ref = x.float() @ W.float().t()
         err = float((out - ref).abs().max())
         assert err <= 2e-4 * float(ref.abs().max()) + 1e-5, (M, N, K, S.value, err)
+        # the same product with the activations in the operand layout the forward keeps them in (16-row tiles)
+        Mp = (M + 15) // 16 * 16
+        xt = torch.zeros(Mp * K, dtype=torch.bfloat16, device="cuda")
+        hip.L.check(hip.lib.sd_pack_activation_bf16(x.data_ptr(), xt.data_ptr(), M, K, _st()))
+        xpad = torch.zeros(Mp, K, dtype=torch.bfloat16, device="cuda")
+        xpad[:M] = x
+        assert torch.equal(xt, xpad.view(Mp // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1))
+        out2 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        hip.L.check(hip.lib.sd_gemm_bf16(Wp.data_ptr(), xt.data_ptr(), 1, M, N, K, part.data_ptr(), part.numel(),
+                                         out2.data_ptr(), C.byref(S), _st()))
+        assert torch.equal(out2, out), (M, N, K)
 
 
 def test_norm_sample_fused_matches_two_step(hip):

@@ -29,19 +29,21 @@ def bench(name, N, K, M=5, units=None, iters=30):
         Wp.append(o)
     torch.cuda.synchronize()
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+    xt = torch.zeros((M + 15) // 16 * 16 * K, device="cuda", dtype=torch.bfloat16)      # operand layout of the forward
+    check(lib.sd_pack_activation_bf16(x.data_ptr(), xt.data_ptr(), M, K, None))
     part = torch.empty(64 * 64 * N, dtype=torch.float32, device="cuda")
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
     S = C.c_int(0)
     st = torch.cuda.current_stream().cuda_stream
     for i in range(3):
-        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(),
+        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), xt.data_ptr(), 1, M, N, K, part.data_ptr(), part.numel(),
                                out.data_ptr(), C.byref(S), st))
     ref = x.float() @ W[2 % copies].float().t()
     err = float((out - ref).abs().max() / ref.abs().max())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(iters):
-        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(),
+        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), xt.data_ptr(), 1, M, N, K, part.data_ptr(), part.numel(),
                                None, None, st))
     e1.record()
     torch.cuda.synchronize()

@@ -23,11 +23,11 @@ def run(N, K, copies, iters=40, M=5):
     part = torch.empty(16 * 16 * N, dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     for i in range(5):
-        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(), None, None, st))
+        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), 0, M, N, K, part.data_ptr(), part.numel(), None, None, st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(iters):
-        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), M, N, K, part.data_ptr(), part.numel(), None, None, st))
+        check(lib.sd_gemm_bf16(Wp[i % copies].data_ptr(), x.data_ptr(), 0, M, N, K, part.data_ptr(), part.numel(), None, None, st))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
