@@ -108,11 +108,11 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 static int gemm_ntw(int N, int M) {
     if (M <= 16) return 1;
     const int ntl = N / 16;
-    // n-tiles per wave: more of them amortise the activation fragment loads, fewer give more workgroups (the fused
-    // epilogues run with SB = 1).  Whole 13b forward, tools/forward_rows_bench.py: 20 rows 6.33 ms with 4 tiles,
-    // 6.04 with 2; 40 rows 7.16 / 6.96; 64 rows 7.77 / 8.94.  8 tiles: register pressure, slower everywhere.
+    // n-tiles per wave: more of them amortise the activation fragment loads, fewer give more workgroups.  Stream-batched
+    // decode, 4 / 6 / 8 / 10 streams x 5 rows (bench.py --batch-streams): 529 / 727 / 861 / 990 tok/s with 4 tiles,
+    // 504 / 753 / 808 / 908 with 2; 8 tiles: register pressure, slower everywhere.
     const char *env = getenv("SD_GEMM_NTW");
-    const int want = env ? atoi(env) : (M <= 48 ? 2 : 4);
+    const int want = env ? atoi(env) : 4;
     if (want >= 8 && ntl % 8 == 0) return 8;
     if (want >= 4 && ntl % 4 == 0) return 4;
     if (want >= 2 && ntl % 2 == 0) return 2;

@@ -817,3 +817,55 @@ def test_evaluation_driver_runs_offline(tmp_path):
     assert "large model total time" in text and "google speculative decoding (with KVCache) total time" in text
     assert "iid multi-draft speculative decoding (gamma 4, width 2) total time" in text
     assert text.count("average accepted len") == 2 and text.count("power/token:") == 3
+
+
+@pytest.mark.parametrize("L,gamma,max_len,width", [(1, 4, 6, 1), (9, 1, 7, 1), (9, 16, 20, 1), (12, 4, 0, 1), (7, 5, 3, 1),
+                                                   (1, 3, 5, 3), (9, 4, 0, 2), (6, 2, 9, 8)],
+                         ids=["prompt1", "gamma1", "gamma16", "maxlen0", "T_mid_iteration", "multi_prompt1", "multi_maxlen0",
+                              "multi_width8"])
+def test_edge_shapes_vs_oracle(hip, L, gamma, max_len, width):
+    """Edge shapes of the loops (one-token prompt, gamma 1 and 16, max_len 0, a target length reached in the middle of an
+    iteration, width 8): the oracle (pinned to the reference by G4/G5/G7) runs with live noise that is recorded, the HIP
+    path replays that noise and must produce the same tokens and statistics."""
+    from llmspeculativesampling_amd.synth import perturb_state_dict
+    cfg = load_config("tiny-llama-target")
+    dsd = make_state_dict(cfg, 11)
+    tsd = perturb_state_dict(dsd, 12, 0.15)
+    prompt = torch.from_numpy(np.random.default_rng([L, gamma]).integers(3, cfg.vocab_size, size=(1, L)))
+    rec = oracle.RecordingNoise()
+    torch.manual_seed(1000 + L + gamma)
+    od, ot = oracle.RefCausalLM(cfg, dsd), oracle.RefCausalLM(cfg, tsd)
+    kw = dict(gamma=gamma, top_k=20, top_p=0.9, details=True)
+    if width == 1:
+        want, dw = oracle.speculative_sampling(prompt, od, ot, 2, None, max_len, noise=rec, **kw)
+    else:
+        want, dw = oracle.multi_speculative_sampling(prompt, od, ot, 2, None, max_len, width=width, strategy="iid",
+                                                     noise=rec, **kw)
+    dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.float32)
+    tm = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.float32)
+    nz = hip.noise.ReplayNoise(rec.events, "cuda")
+    if width == 1:
+        got, dg = hip.S.speculative_sampling(prompt.cuda(), dm, tm, 2, None, max_len, rng=nz, **kw)
+    else:
+        got, dg = hip.S.multi_speculative_sampling(prompt.cuda(), dm, tm, 2, None, max_len, width=width, strategy="iid",
+                                                   rng=nz, **kw)
+    assert torch.equal(got.cpu(), want)
+    assert dg["acc_len"] == dw["acc_len"] and dg["target_call_times"] == dw["target_call_times"]
+    assert nz.exhausted()
+    if max_len == 0:
+        assert torch.equal(got.cpu(), prompt) and dg["target_call_times"] == 0
+
+
+def test_autoregressive_edge_shapes_vs_oracle(hip):
+    """autoregressive_sampling: N = 0 returns the prompt, a one-token prompt, N = 1."""
+    cfg = load_config("tiny-opt-post")
+    sd = make_state_dict(cfg, 43)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    for L, N in ((5, 0), (1, 4), (3, 1)):
+        prompt = torch.from_numpy(np.random.default_rng([L, N]).integers(3, cfg.vocab_size, size=(1, L)))
+        rec = oracle.RecordingNoise()
+        torch.manual_seed(50 + L)
+        want = oracle.autoregressive_sampling(prompt, oracle.RefCausalLM(cfg, sd), N, 2, top_k=10, top_p=0.9, noise=rec)
+        got = hip.S.autoregressive_sampling(prompt.cuda(), m, N, 2, top_k=10, top_p=0.9,
+                                            rng=hip.noise.ReplayNoise(rec.events, "cuda"))
+        assert torch.equal(got.cpu(), want)
