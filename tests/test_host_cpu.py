@@ -184,3 +184,18 @@ def test_harness_chatalpaca_reader_and_power_sum(tmp_path):
     assert "total time 6.0 s, total tokens 40, average time 0.15 s/token" in out[0]
     assert out[2].startswith("average accepted len 3.0, target call times 10, acc rate 0.6")
     assert out[-1] == "power/token: 2.25"
+
+
+def test_sampling_package_exports_every_reference_name():
+    """The reference harness imports nine names from ``sampling`` (sampling/__init__.py:1-7, evaluation.py:13-14): all of
+    them resolve here; the out-of-scope variants raise NotImplementedError when called."""
+    import llmspeculativesampling_amd.sampling as S
+    ref_all = ["speculative_sampling", "speculative_sampling_v2", "autoregressive_sampling", "multi_speculative_sampling",
+               "beam_speculative_sampling", "BiLD_sampling", "mjsd_speculative_sampling", "random_width_beam_sampling",
+               "beam_speculative_sampling_v2"]
+    for n in ref_all:
+        assert callable(getattr(S, n)) and n in S.__all__
+    for n in ("speculative_sampling_v2", "beam_speculative_sampling", "BiLD_sampling", "mjsd_speculative_sampling",
+              "random_width_beam_sampling", "beam_speculative_sampling_v2"):
+        with pytest.raises(NotImplementedError):
+            getattr(S, n)(None, None, None)
