@@ -217,6 +217,10 @@ typedef struct sd_model sd_model;
 /* Copies the config and the pointer table into a host handle (weights stay where they are). */
 int sd_model_create(const sd_model_config *cfg, const sd_model_weights *w, sd_model **out);
 int sd_model_destroy(sd_model *m);
+/* Rows one sd_session_forward call may carry for this model: 256 (prefill chunks; the many-row GEMM kernel needs every
+ * per-layer weight matrix to have N % 128 == 0 and K % 64 == 0, K >= 512) or 64.  sd_session_create and
+ * sd_session_scratch_bytes clamp their max_rows to it. */
+int sd_model_max_rows(const sd_model *m);
 
 /* Repack a row-major bf16 [N][K] matrix (N % 16 == 0, K % 32 == 0) into the streaming layout the
  * GEMM kernels read: 1 KiB tiles [N/16][K/32][lane 0..63][8 bf16], lane = 16*(k/8 % 4) + n % 16. */
@@ -229,7 +233,8 @@ int sd_pack_activation_bf16(const void *x_rowmajor, void *x_tiled, int M, int K,
 
 /* The weight-streaming GEMM on its own (unit tests, kernel-level roofline runs):
  * part[s][m][n] = sum over k-slice s of x[m][k] * W[n][k] for a tile-packed bf16 W, then (if out != NULL)
- * out[m][n] = sum_s part[s][m][n] in fp32.  M <= 64.  x: plain rows (x_tiled == 0) or sd_pack_activation_bf16's
+ * out[m][n] = sum_s part[s][m][n] in fp32.  M <= 64 (<= 256 with x_tiled and N % 128 == 0: from 33 rows on the
+ * LDS-tiled kernel runs).  x: plain rows (x_tiled == 0) or sd_pack_activation_bf16's
  * layout (x_tiled != 0, what the forward uses).  part must hold splits * roundup(M,16) * N floats; the split count the
  * policy chose comes back in *splits_out. */
 int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, int M, int N, int K, float *part,

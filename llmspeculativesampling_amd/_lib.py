@@ -87,6 +87,7 @@ SYMBOLS = [
     ("sd_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
     ("sd_model_create", _I, [C.POINTER(SdModelConfig), C.POINTER(SdModelWeights), C.POINTER(_VP)]),
     ("sd_model_destroy", _I, [_VP]),
+    ("sd_model_max_rows", _I, [_VP]),
     ("sd_pack_weight_bf16", _I, [_VP, _VP, _I, _I, _VP]),
     ("sd_pack_activation_bf16", _I, [_VP, _VP, _I, _I, _VP]),
     ("sd_gemm_bf16", _I, [_VP, _VP, _I, _I, _I, _I, _VP, C.c_size_t, _VP, C.POINTER(C.c_int), _VP]),

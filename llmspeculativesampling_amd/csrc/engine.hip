@@ -159,14 +159,59 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
     *ks_per_out = ks_per;
 }
 
+// Which kernel a bf16 GEMM over M rows takes and how its k-range is cut.  Prefill chunks of more than 64 rows take the
+// LDS-tiled kernel: tools/gemm_bench.py at the 13b shapes, one tiled pass over 128 / 256 rows costs 171 / 257 us per
+// layer against 324 / 648 us for 2 / 4 streaming passes of 64.  At 33..64 rows it is ~10 % ahead as a bare GEMM (qkv
+// 35.6 us against 41.1, gate/up 59.8 / 63.8) but needs slabs plus the stand-alone epilogues where the streaming kernel
+// fuses them, and the whole forward comes out even (bench.py --batch-streams 8 / 12), so those stay on the streaming
+// kernel.  Slab count: about 480 workgroups (measured optimum for all four shapes at 64, 128 and 256 rows).
+#define SD_MAX_FWD_ROWS 256
+struct GemmPlan { bool tiled; int S, ksp, mtw; };
+static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true) {
+    GemmPlan p = {};
+    const int KS = K / 32, Mpad = (int)align_up(M, 16);
+    static const int tiled_min = getenv("SD_GEMM_TILED_MIN") ? atoi(getenv("SD_GEMM_TILED_MIN")) : 65;
+    if (x_tiled && M >= tiled_min && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
+        p.tiled = true;
+        p.mtw = Mpad <= 64 ? 2 : 4;
+        const int MB = (Mpad / 16 + 2 * p.mtw - 1) / (2 * p.mtw), blocks = MB * (N / 16 / 8);
+        int S = std::max(1, (480 + blocks / 2) / blocks);
+        S = std::min(S, std::max(1, KS / 16));
+        p.ksp = (int)align_up((KS + S - 1) / S, 2);
+        p.S = (KS + p.ksp - 1) / p.ksp;
+        return p;
+    }
+    gemm_split(N, K, std::min(M, 64), &p.S, &p.ksp);
+    return p;
+}
+
+static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, int Mpad, int N, int K,
+                              const GemmPlan &pl, hipStream_t st) {
+    const int MB = (Mpad / 16 + 2 * pl.mtw - 1) / (2 * pl.mtw), NB = N / 16 / 8;
+    const dim3 grid(MB * NB * pl.S);
+    const size_t lds = (size_t)2 * (8 + 2 * pl.mtw) * 2 * 1024;   // 2 buffers x (8 W + 2*MTW X tiles) x KT = 2 k-tiles
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<2, 4, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<4, 4, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    if (pl.mtw == 2)
+        hipLaunchKernelGGL((gemm_bf16_tiled<2, 4, 2>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
+                           Mpad, N, K, pl.S, pl.ksp);
+    else
+        hipLaunchKernelGGL((gemm_bf16_tiled<4, 4, 2>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
+                           Mpad, N, K, pl.S, pl.ksp);
+}
+
 static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
     if (c.dtype != SD_BF16) return (size_t)rows * N;
     size_t best = 0;
-    for (int m : {1, 16, 17, 32, 33, 48, 49, rows}) {            // every (m-tile count, tiles-per-wave) class the policy has
-        if (m > rows) continue;
-        int S, ksp;
-        gemm_split(N, K, m, &S, &ksp);
-        best = std::max(best, (size_t)S * align_up(m, 16) * N);
+    for (int m = 1; m <= rows; m = (m % 16 == 0 ? m + 1 : (int)align_up(m, 16))) {       // every plan class: 1, 16, 17, 32, 33, ...
+        const GemmPlan pl = gemm_plan(N, K, m);
+        best = std::max(best, (size_t)pl.S * align_up(m, 16) * N);
     }
     return best;
 }
@@ -214,8 +259,22 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     return p;
 }
 
+// Rows one sd_session_forward call may carry: 256 when every per-layer GEMM of the model can take the tiled kernel
+// (or the model is fp32, whose simple GEMM has no row limit), else the streaming kernel's 64.
+extern "C" int sd_model_max_rows(const sd_model *m) {
+    if (!m) return 0;
+    const sd_model_config &c = m->cfg;
+    if (c.dtype != SD_BF16) return SD_MAX_FWD_ROWS;
+    const int ed = embed_dim(c);
+    const int shapes[][2] = {{qkv_cols(c), c.hidden}, {c.hidden, c.hidden}, {gu_cols(c), c.hidden}, {c.hidden, c.inter},
+                             {c.hidden, ed}, {ed, c.hidden}};
+    for (int i = 0; i < (ed != c.hidden ? 6 : 4); ++i)
+        if (!gemm_plan(shapes[i][0], shapes[i][1], SD_MAX_FWD_ROWS).tiled) return SD_MAX_ROWS;
+    return SD_MAX_FWD_ROWS;
+}
+
 extern "C" size_t sd_session_scratch_bytes(const sd_model *m, int max_rows) {
-    return plan_scratch(m->cfg, max_rows).total;
+    return plan_scratch(m->cfg, std::min(max_rows, sd_model_max_rows(m))).total;
 }
 
 extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *kv_arena, void *scratch,
@@ -229,6 +288,7 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     sd_session *s = new sd_session();
     s->m = m;
     s->max_seq = max_seq;
+    max_rows = std::min(max_rows, sd_model_max_rows(m));
     s->max_rows = max_rows;
     s->kv = (char *)kv_arena;
     s->scratch = (char *)scratch;
@@ -354,14 +414,18 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
     if (c.dtype == SD_BF16) {
-        int S, ksp;
-        gemm_split(N, K, M, &S, &ksp);
+        const GemmPlan pl = gemm_plan(N, K, M, xtab == nullptr);          // a row gather (lm_head) keeps the streaming kernel
+        const int S = pl.S, ksp = pl.ksp;
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
-        GemmEpi e = {};
-        if (xtab) { e.use_xmap = 1; e.tab = *xtab; }
-        const int rc = dispatch_gemm_bf16<EPI_PART>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
-        if (rc != SD_OK) return rc;
+        if (pl.tiled) {
+            launch_gemm_tiled(W, X, s->part, M, Mpad, N, K, pl, st);
+        } else {
+            GemmEpi e = {};
+            if (xtab) { e.use_xmap = 1; e.tab = *xtab; }
+            const int rc = dispatch_gemm_bf16<EPI_PART>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
+            if (rc != SD_OK) return rc;
+        }
         go->S = S;
         go->stride_s = (size_t)Mpad * N;
     } else {
@@ -480,8 +544,9 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     }
 
     for (int l = 0; l < L; ++l) {
-        // qkv projection -> rope / scale -> q buffer + in-place KV append
-        if (fused) {
+        // qkv projection -> rope / scale -> q buffer + in-place KV append (fused into the GEMM's epilogue unless the
+        // row count takes the tiled kernel, which leaves slabs for the stand-alone epilogue)
+        if (fused && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
             GemmEpi e = {};
             e.out = (bf16_t *)qb; e.bias = (const bf16_t *)m->bqkv[l];
             e.cos_t = (const bf16_t *)m->w.rope_cos; e.sin_t = (const bf16_t *)m->w.rope_sin;
@@ -496,7 +561,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             hipLaunchKernelGGL((qkv_epilogue_kernel<T>), dim3(n_new, c.n_heads + 2 * c.n_kv_heads),
                                dim3(std::max(D / 2, 64)), 0, st, s->part, go.S, go.stride_s, qkv_cols(c),
                                (const T *)m->bqkv[l], (const T *)m->w.rope_cos, (const T *)m->w.rope_sin, c.arch,
-                               1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb);
+                               1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
         {
@@ -522,7 +587,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         // MLP
-        if (fused) {
+        if (fused && !gemm_plan(gu_cols(c), H, n_new).tiled) {
             GemmEpi e = {};
             e.out = (bf16_t *)ac; e.bias = (const bf16_t *)m->bfc1[l]; e.n_out = I;
             rc = llama ? run_gemm_fused<EPI_ACT_SILU>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)
@@ -532,7 +597,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             if ((rc = run_gemm(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_ACT, st);
             hipLaunchKernelGGL((act_kernel<T>), dim3((I + 255) / 256, n_new), dim3(256), 0, st, s->part, go.S,
-                               go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac);
+                               go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
         if ((rc = run_gemm(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
@@ -579,6 +644,16 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
 // fill the attention groups and the lm_head row map of a table whose rows are already laid out stream by stream
 static void finish_table(RowTab &tab) {
     tab.n_groups = 0;
+    if (tab.contig) {                               // up to 256 rows = 32 groups of ATT_TQ consecutive positions
+        for (int r = 0; r < tab.n_rows; r += ATT_TQ) {
+            const int g = tab.n_groups++;
+            tab.grp_row0[g] = r;
+            tab.grp_n[g] = std::min(ATT_TQ, tab.n_rows - r);
+            tab.grp_pos[g] = tab.pos0 + r;
+            tab.grp_stream[g] = 0;
+        }
+        return;
+    }
     int r = 0;
     while (r < tab.n_rows) {
         int n = 1;
@@ -606,9 +681,9 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     SD_REQUIRE(n_new >= 1 && pos0 >= 0, "sd_session_forward: n_new=%d pos0=%d", n_new, pos0);
     SD_REQUIRE(n_logits >= 0 && n_logits <= n_new, "sd_session_forward: n_logits=%d of n_new=%d", n_logits, n_new);
     SD_REQUIRE(n_logits == 0 || logits_out, "sd_session_forward: logits_out is null");
-    if (n_new > s->max_rows || n_new > SD_MAX_ROWS || pos0 + n_new > s->max_seq) {
-        sd_set_error("sd_session_forward: n_new=%d (max_rows %d, <=64), pos0+n_new=%d (max_seq %d)", n_new,
-                     s->max_rows, pos0 + n_new, s->max_seq);
+    if (n_new > s->max_rows || n_new > SD_MAX_FWD_ROWS || n_logits > SD_MAX_ROWS || pos0 + n_new > s->max_seq) {
+        sd_set_error("sd_session_forward: n_new=%d (max_rows %d, <=%d), n_logits=%d (<=%d), pos0+n_new=%d (max_seq %d)",
+                     n_new, s->max_rows, SD_MAX_FWD_ROWS, n_logits, SD_MAX_ROWS, pos0 + n_new, s->max_seq);
         return SD_ERR_CAPACITY;
     }
     RowTab tab = {};
@@ -618,8 +693,13 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     tab.tok_base[0] = tokens - pos0;            // indexed by absolute position, only ever read at pos0 .. pos0+n_new-1
     tab.kv_base[0] = s->kv;
     tab.max_seq[0] = s->max_seq;
-    for (int i = 0; i < n_new; ++i) { tab.row_pos[i] = pos0 + i; tab.row_stream[i] = 0; }
-    for (int i = 0; i < n_logits; ++i) tab.xmap[i] = (unsigned char)(n_new - n_logits + i);
+    if (n_new > SD_MAX_ROWS) {                      // prefill chunk: positions are implicit
+        tab.contig = 1;
+        tab.pos0 = pos0;
+    } else {
+        for (int i = 0; i < n_new; ++i) { tab.row_pos[i] = pos0 + i; tab.row_stream[i] = 0; }
+    }
+    for (int i = 0; i < n_logits; ++i) tab.xmap[i] = (unsigned char)(n_new - n_logits + i);   // n_new <= 256
     finish_table(tab);
     return run_forward(s, tab, pos0 + n_new, logits_out, ld_logits, stream);
 }
@@ -683,10 +763,24 @@ extern "C" int sd_pack_activation_bf16(const void *x_rowmajor, void *x_tiled, in
 extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, int M, int N, int K, float *part,
                             size_t part_floats, float *out, int *splits_out, void *stream) {
     SD_REQUIRE(w_packed && x && part, "sd_gemm_bf16: null argument");
-    SD_REQUIRE(M >= 1 && M <= 64 && N % 16 == 0 && K % 32 == 0, "sd_gemm_bf16: need 1<=M<=64, N%%16==0, K%%32==0");
-    int S, ksp;
-    gemm_split(N, K, M, &S, &ksp);
+    SD_REQUIRE(M >= 1 && M <= SD_MAX_FWD_ROWS && N % 16 == 0 && K % 32 == 0,
+               "sd_gemm_bf16: need 1<=M<=%d, N%%16==0, K%%32==0", SD_MAX_FWD_ROWS);
+    const GemmPlan pl = gemm_plan(N, K, M, x_tiled != 0);
+    int S = pl.S, ksp = pl.ksp;
     const int Mpad = (int)align_up(M, 16);
+    if (pl.tiled) {
+        SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
+        launch_gemm_tiled(w_packed, x, part, M, Mpad, N, K, pl, (hipStream_t)stream);
+        SD_LAUNCH_CHECK();
+        if (out) {
+            hipLaunchKernelGGL(reduce_f32_kernel, dim3((M * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, S,
+                               (size_t)Mpad * N, M * N, out);
+            SD_LAUNCH_CHECK();
+        }
+        if (splits_out) *splits_out = S;
+        return SD_OK;
+    }
+    SD_REQUIRE(M <= 64, "sd_gemm_bf16: more than 64 rows need the tile layout (x_tiled) and N %% 128 == 0");
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
     GemmEpi e = {};

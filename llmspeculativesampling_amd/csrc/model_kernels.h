@@ -17,6 +17,9 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 #define SD_MAX_GROUPS 32
 struct RowTab {
     int n_rows, n_streams, n_groups, n_logit_rows;
+    int contig, pos0;                               // contig: one stream, row m at position pos0 + m (the only form with
+                                                    // more than SD_MAX_ROWS rows: prefill chunks of up to 256); the two
+                                                    // per-row arrays below are then unused
     int row_pos[SD_MAX_ROWS];                       // absolute position of row m in its sequence
     unsigned char row_stream[SD_MAX_ROWS];          // stream of row m
     unsigned char xmap[SD_MAX_ROWS];                // rows of the hidden state that feed the lm_head, in output order
@@ -39,6 +42,9 @@ __device__ __forceinline__ size_t xoff(int m, int k, int K) {
     else
         return (size_t)m * K + k;
 }
+
+__device__ __forceinline__ int tab_pos(const RowTab &t, int m) { return t.contig ? t.pos0 + m : t.row_pos[m]; }
+__device__ __forceinline__ int tab_stream(const RowTab &t, int m) { return t.contig ? 0 : (int)t.row_stream[m]; }
 
 enum { NORM_RMS = 0, NORM_LN = 1 };
 enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual feeds the next GEMM / replaces x / no norm
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
                     const f32x4 r = folded(pp, l);
                     const int head = col / e.D, within = col - head * e.D;
                     const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
-                    const int strm = e.tab.row_stream[m], pos = e.tab.row_pos[m], mseq = e.tab.max_seq[strm];
+                    const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
                     bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
                     bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
                                        : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
@@ -234,6 +240,93 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Many-row GEMM (prefill, wide stream batches): part[sb][m][n] = sum_{k in slab sb} X[m][k] * W[n][k]
+// One workgroup = 2 x 2 waves on a (2*NTWV n-tiles) x (2*MTW m-tiles) block of the output; per k-step (32 columns of
+// K) its W and X tiles - both already stored in MFMA fragment order, 1 KiB each - are copied once into LDS (double
+// buffered) and every wave reads the fragments of its quadrant from there, so a W tile feeds 2*MTW and an X tile
+// 2*NTWV MFMAs per global load instead of MTW / NTW in the streaming kernel.  No in-workgroup k-split: the k-range is
+// cut across workgroups (slabs) only when the block count is too small.
+// ------------------------------------------------------------------------------------------
+template <int MTW, int NTWV, int KT>
+__global__ __launch_bounds__(256) void gemm_bf16_tiled(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
+                                                      float *__restrict__ part, int M, int Mpad, int N, int K, int SB,
+                                                      int ks_per_blk) {
+    constexpr int WT = 2 * NTWV, XT = 2 * MTW, TT = WT + XT;      // tiles per k-tile column: W, X, total
+    constexpr int NL = TT * KT;                                   // tiles per k-step (KT k-tiles = 32*KT columns of K)
+    constexpr int LPT = (NL + 3) / 4;                             // tile loads per wave per k-step
+    extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+    u32x4 (*sm)[NL][64] = reinterpret_cast<u32x4 (*)[NL][64]>(dyn_smem);          // [2][NL][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wn = wv & 1, wm = wv >> 1;
+    const int KS = K >> 5, NB = (N >> 4) / WT, MB = ((Mpad >> 4) + XT - 1) / XT;
+    int b = blockIdx.x;
+    const int mb = b % MB; b /= MB;                               // m-blocks of one n-block are neighbours (W reuse in L2)
+    const int nb = b % NB, sb = b / NB;
+    const int nt0 = nb * WT, mt0 = mb * XT, mt_end = Mpad >> 4;
+    const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);      // ks_per_blk is a multiple of KT
+    // slot i of a k-step: kk = i / TT (k-tile inside the step), tt = i % TT: tt < WT -> W tile nt0 + tt, else X tile
+    // mt0 + tt - WT; wave wv copies slots wv, wv + 4, ...
+    const u32x4 *src[LPT];
+    bool ok[LPT], isw[LPT];
+#pragma unroll
+    for (int r = 0; r < LPT; ++r) {
+        const int i = wv + 4 * r, kk = i / TT, tt = i - kk * TT;
+        isw[r] = tt < WT;
+        ok[r] = i < NL && (isw[r] || mt0 + tt - WT < mt_end);
+        src[r] = !ok[r] ? Wp : (isw[r] ? Wp + ((size_t)(nt0 + tt) * KS + kb0 + kk) * 64 + lane
+                                       : Xp + ((size_t)(mt0 + tt - WT) * KS + kb0 + kk) * 64 + lane);
+    }
+    f32x4 acc[NTWV][MTW];
+#pragma unroll
+    for (int j = 0; j < NTWV; ++j)
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 stage[LPT];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r) {
+            stage[r] = ok[r] ? (isw[r] ? __builtin_nontemporal_load(src[r]) : *src[r]) : u32x4{0u, 0u, 0u, 0u};
+            src[r] += (size_t)KT * 64;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < LPT; ++r)
+            if (wv + 4 * r < NL) sm[buf][wv + 4 * r][lane] = stage[r];
+    };
+    if (kb0 < kb1) { fetch(); put(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int ks = kb0; ks < kb1; ks += KT) {
+        const bool more = ks + KT < kb1;
+        if (more) fetch();                                        // next k-step's tiles travel while this one is multiplied
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            u32x4 wf[NTWV], xf[MTW];
+#pragma unroll
+            for (int j = 0; j < NTWV; ++j) wf[j] = sm[cur][kk * TT + wn * NTWV + j][lane];
+#pragma unroll
+            for (int t = 0; t < MTW; ++t) xf[t] = sm[cur][kk * TT + WT + wm * MTW + t][lane];
+#pragma unroll
+            for (int j = 0; j < NTWV; ++j)
+#pragma unroll
+                for (int t = 0; t < MTW; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]),
+                                                                       __builtin_bit_cast(bf16x8, xf[t]), acc[j][t], 0, 0, 0);
+        }
+        if (more) put(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NTWV; ++j)
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+            const int m = (mt0 + wm * MTW + t) * 16 + (lane & 15), n = (nt0 + wn * NTWV + j) * 16 + (lane >> 4) * 4;
+            if (m < M) *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + n) = acc[j][t];
+        }
 }
 
 // fp32 storage (parity runs on small models): one wave per output column, lanes stride K.
@@ -324,8 +417,8 @@ template <typename T>
 __global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, const T *__restrict__ pos_table,
                              int pos_off, T *__restrict__ out, int tiled) {
     const int row = blockIdx.x;
-    const int pos = tab.row_pos[row];
-    const int tok = tab.tok_base[tab.row_stream[row]][pos];
+    const int pos = tab_pos(tab, row);
+    const int tok = tab.tok_base[tab_stream(tab, row)][pos];
     const T *src = table + (size_t)tok * dim;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * dim : nullptr;
     for (int i = threadIdx.x; i < dim; i += blockDim.x) {
@@ -347,7 +440,7 @@ template <typename T>
 __global__ void reduce_addpos_kernel(const float *__restrict__ part, int S, size_t stride_s, int N,
                                      const T *__restrict__ pos_table, RowTab tab, int pos_off, T *__restrict__ out) {
     const int row = blockIdx.x;
-    const int pos0 = tab.row_pos[row] - row;
+    const int pos0 = tab_pos(tab, row) - row;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         float v = reduce_part<T>(part, S, stride_s, (size_t)row * N + i, nullptr, i);
         if (pos_table) v = rnd<T>(v + to_f(pos_table[(size_t)(pos0 + row + pos_off) * N + i]));
@@ -507,17 +600,19 @@ template <typename T>
 __global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_t stride_s, int Nqkv,
                                     const T *__restrict__ bias, const T *__restrict__ cos_t,
                                     const T *__restrict__ sin_t, int arch, float q_scale, int Hq, int Hkv, int D,
-                                    RowTab tab, int layer, T *__restrict__ qbuf) {
+                                    RowTab tab, int layer, T *__restrict__ qbuf, int fused) {
     const int row = blockIdx.x, head = blockIdx.y, d = threadIdx.x, hd = D >> 1;
     if (d >= hd) return;
-    const int strm = tab.row_stream[row], pos = tab.row_pos[row], max_seq = tab.max_seq[strm];
+    const int strm = tab_stream(tab, row), pos = tab_pos(tab, row), max_seq = tab.max_seq[strm];
     T *karena = (T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
     T *varena = karena + (size_t)Hkv * max_seq * D;
-    const int col0 = head * D + d, col1 = col0 + hd;
+    const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
+    // fused weight layout (Llama): the rows of a q / k head are stored d0, d0+D/2, d1, d1+D/2, ...
+    const bool paired = fused && arch == SD_ARCH_LLAMA && (is_q || is_k);
+    const int col0 = head * D + (paired ? 2 * d : d), col1 = paired ? col0 + 1 : col0 + hd;
     const float v0 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col0, bias, col0);
     const float v1 = reduce_part<T>(part, S, stride_s, (size_t)row * Nqkv + col1, bias, col1);
     float o0 = v0, o1 = v1;
-    const bool is_q = head < Hq, is_k = !is_q && head < Hq + Hkv;
     if (arch == SD_ARCH_LLAMA && (is_q || is_k)) {
         const float c = to_f(cos_t[(size_t)pos * hd + d]);
         const float s = to_f(sin_t[(size_t)pos * hd + d]);
@@ -831,14 +926,16 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void act_kernel(const float *__restrict__ part, int S, size_t stride_s, int I, int Ncols, int arch,
-                           const T *__restrict__ bias, T *__restrict__ act) {
+                           const T *__restrict__ bias, T *__restrict__ act, int fused) {
     const int row = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= I) return;
     float a;
     if (arch == SD_ARCH_LLAMA) {
-        const float g = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + c, nullptr, c);
-        const float u = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + I + c, nullptr, c);
+        // fused weight layout: 8 gate rows, the same 8 up rows, 8 gate rows, ...
+        const int gc = fused ? (c >> 3) * 16 + (c & 7) : c, uc = fused ? gc + 8 : I + c;
+        const float g = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + gc, nullptr, c);
+        const float u = reduce_part<T>(part, S, stride_s, (size_t)row * Ncols + uc, nullptr, c);
         const float sg = rnd<T>(g / (1.0f + expf(-g)));
         a = rnd<T>(sg * u);
     } else {

@@ -20,7 +20,8 @@ from . import _lib
 from ._lib import lib, check
 from .config import ModelConfig, config_from_hf
 
-MAX_ROWS_PER_FORWARD = 64       # one sd_session_forward call; longer prompts are chunked
+MAX_ROWS_PER_FORWARD = 64       # rows of one stream-batched pass, and logit rows of any one call
+MAX_PREFILL_ROWS = 256          # rows of one single-sequence sd_session_forward call; longer prompts are chunked
 
 
 def _stream() -> int:
@@ -208,7 +209,7 @@ class SpecDecModel:
         m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
         return m
 
-    def new_session(self, max_seq: int, max_rows: int = MAX_ROWS_PER_FORWARD) -> "Session":
+    def new_session(self, max_seq: int, max_rows: int = MAX_PREFILL_ROWS) -> "Session":
         return Session(self, max_seq, max_rows)
 
 
@@ -216,18 +217,19 @@ class Session:
     """KV arena [L][2][H_kv][max_seq][D] + scratch for one sequence; ``cache_len`` is the number of
     positions held, so rollback is an assignment (reference kvcache_model.py:359-436)."""
 
-    def __init__(self, model: SpecDecModel, max_seq: int, max_rows: int = MAX_ROWS_PER_FORWARD):
+    def __init__(self, model: SpecDecModel, max_seq: int, max_rows: int = MAX_PREFILL_ROWS):
         cfg = model.cfg
         self.model = model
         self.max_seq = int(min(max_seq, model.max_pos))
-        self.max_rows = int(min(max_rows, MAX_ROWS_PER_FORWARD))
+        self.max_rows = int(min(max_rows, MAX_PREFILL_ROWS, lib.sd_model_max_rows(model.handle)))
         dev = model.device
         self.kv = torch.zeros((cfg.num_hidden_layers, 2, cfg.num_key_value_heads, self.max_seq, cfg.head_dim),
                               dtype=model.dtype, device=dev)
         assert self.kv.numel() * self.kv.element_size() == lib.sd_session_kv_bytes(model.handle, self.max_seq)
         nbytes = lib.sd_session_scratch_bytes(model.handle, self.max_rows)
         self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.logits = torch.empty((self.max_rows, cfg.vocab_size), dtype=torch.float32, device=dev)
+        self.logits = torch.empty((min(self.max_rows, MAX_ROWS_PER_FORWARD), cfg.vocab_size), dtype=torch.float32,
+                                  device=dev)
         h = C.c_void_p()
         check(lib.sd_session_create(model.handle, self.max_seq, self.max_rows, self.kv.data_ptr(),
                                     self.scratch.data_ptr(), C.byref(h)), "sd_session_create")
@@ -258,7 +260,9 @@ class Session:
         done = 0
         while done < n:
             m = min(self.max_rows, n - done)
-            lo = max(first_logit_row, done)            # rows of this chunk that need logits
+            lo = max(first_logit_row, done)            # rows of this chunk that need logits (at most 64 per call)
+            if done + m - lo > MAX_ROWS_PER_FORWARD:
+                m = lo + MAX_ROWS_PER_FORWARD - done
             nl = max(0, done + m - lo)
             dst = logits_out.data_ptr() + (lo - first_logit_row) * ld * 4 if nl else None
             check(lib.sd_session_forward(self.handle, tokens.data_ptr() + done * 4, m, pos0 + done, nl, dst, ld, st),

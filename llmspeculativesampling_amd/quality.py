@@ -20,7 +20,7 @@ def get_score(output: torch.Tensor, target_model, input_len: int) -> torch.Tenso
     logits = torch.empty((S, m.cfg.vocab_size), dtype=torch.float32, device=m.device)
     done = 0
     while done < S:                                   # all S rows of logits, max_rows at a time
-        n = min(ses.max_rows, S - done)
+        n = min(64, S - done)                         # logit rows per call
         ses.forward(ids[done:done + n], n, logits_out=logits[done:done + n])
         done += n
     logp = torch.log_softmax(logits[:-1], dim=-1)

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from .._lib import lib, check
-from ..engine import SpecDecModel, Session, as_specdec_model, _stream
+from ..engine import SpecDecModel, Session, as_specdec_model, _stream, MAX_ROWS_PER_FORWARD
 from ..noise import HostTorchNoise
 
 
@@ -89,7 +89,7 @@ class KVCacheModel:
             ev0.record()
         while done < n_rows_out:                        # logits buffer holds max_rows rows at a time
             # feed everything up to the end of this block of output rows
-            blk = min(ses.max_rows, n_rows_out - done)
+            blk = min(MAX_ROWS_PER_FORWARD, n_rows_out - done)
             end = first + done + blk
             logits = ses.forward(seq32[ses.cache_len:end], blk)
             t1 = process_time_ns()

@@ -31,7 +31,7 @@ def bench(name, N, K, M=5, units=None, iters=30):
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     xt = torch.zeros((M + 15) // 16 * 16 * K, device="cuda", dtype=torch.bfloat16)      # operand layout of the forward
     check(lib.sd_pack_activation_bf16(x.data_ptr(), xt.data_ptr(), M, K, None))
-    part = torch.empty(64 * 64 * N, dtype=torch.float32, device="cuda")
+    part = torch.empty(max(64 * 64, 16 * max(M, 16)) * N, dtype=torch.float32, device="cuda")
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
     S = C.c_int(0)
     st = torch.cuda.current_stream().cuda_stream
@@ -60,8 +60,9 @@ if __name__ == "__main__":
         for u in (None, 512, 768, 1024, 1280, 2048, 2560, 4096):
             bench(n, N, K, units=u)
     if not sys.argv[1:]:
-        for M in (1, 5, 16, 17, 32, 48, 64):
-            bench("gate_up", *SHAPES["gate_up"], M=M)
+        for M in (1, 5, 16, 17, 32, 48, 64, 128, 256):
+            for n in ("qkv", "o", "gate_up", "down"):
+                bench(n, *SHAPES[n], M=M)
     if sys.argv[1:] == ["rows"]:
         for ntw in ("4", "8"):
             os.environ["SD_GEMM_NTW"] = ntw
