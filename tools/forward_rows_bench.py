@@ -20,8 +20,8 @@ def main():
     cfg = load_config(os.environ.get("TARGET", "llama-2-13b"))
     m = SpecDecModel.synthetic(cfg, seed=1, dtype=torch.bfloat16)
     ctx = 192
-    toks = torch.from_numpy(np.random.default_rng(0).integers(3, cfg.vocab_size, size=ctx + 64)).to(torch.int32).cuda()
-    ses = m.new_session(ctx + 80)
+    toks = torch.from_numpy(np.random.default_rng(0).integers(3, cfg.vocab_size, size=ctx + 256)).to(torch.int32).cuda()
+    ses = m.new_session(ctx + 260)
     for lo in range(0, ctx, 64):
         ses.forward(toks[lo:lo + 64], 0)
     variants = [v for v in os.environ.get("VARIANTS", "auto").split(",")]     # tiles per wave; auto = the engine's policy
