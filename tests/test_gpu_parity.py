@@ -604,14 +604,20 @@ def test_forward_long_context_split_keys_vs_oracle(hip, name, dtype):
         pos += q
 
 
+@pytest.mark.parametrize("arch", ["llama", "opt"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
-def test_prefill_chunks_over_64_rows_vs_oracle(hip, dtype):
+def test_prefill_chunks_over_64_rows_vs_oracle(hip, dtype, arch):
     """Single-sequence calls carry up to 256 rows (positions implicit in the row table; bf16: the LDS-tiled many-row
     GEMM + stand-alone QKV / activation epilogues on the fused weight layout): a 230-token prompt in one call, 300 more
     in two, then decode steps, against the oracle forward; and the KV rows equal those of 64-row chunks closely."""
     from llmspeculativesampling_amd.config import ModelConfig
-    cfg = ModelConfig(arch="llama", vocab_size=1024, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
-                      num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-5)
+    if arch == "llama":
+        cfg = ModelConfig(arch="llama", vocab_size=1024, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=1024, rms_norm_eps=1e-5)
+    else:
+        cfg = ModelConfig(arch="opt", vocab_size=1024, hidden_size=512, ffn_dim=1024, num_hidden_layers=2,
+                          num_attention_heads=8, max_position_embeddings=1024, do_layer_norm_before=True,
+                          word_embed_proj_dim=512)
     sd = make_state_dict(cfg, 79, dtype=dtype)
     om = oracle.RefCausalLM(cfg, sd)
     m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
