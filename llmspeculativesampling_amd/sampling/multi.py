@@ -20,7 +20,7 @@ from time import process_time_ns
 import numpy as np
 import torch
 
-from .._lib import lib, check, SdMultiItem, SdMultiResult, SdNormRow
+from .._lib import lib, check, SdMultiItem, SdMultiResult, SdNormRow, SpecDecError
 from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD
 from .kvcache_model import KVCacheModel
 from .speculative_sampling import _make_noise
@@ -238,8 +238,10 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
                             break
                 out = host[:cut]
                 break
-    except RuntimeError as e:                                          # swallowed like the reference (:1696-1697)
-        print(e)
+    except SpecDecError:                                               # an engine failure is never swallowed
+        raise
+    except RuntimeError as e:                                          # 'norm logits error' / 'prob error': printed and
+        print(e)                                                       # swallowed like the reference (:1696-1697)
 
     result = torch.tensor([out], dtype=torch.int64, device=prefix.device)
     if verbose:

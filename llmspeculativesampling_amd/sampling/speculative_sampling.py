@@ -166,9 +166,9 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
                 out_tokens = host_seq[:cut]
                 break
             other_time += process_time_ns() - tick
-    except Exception as e:                            # (:2044-2046)
+    except Exception as e:                            # (:2044-2046); the cause stays attached to the traceback
         print(e)
-        raise RuntimeError("s")
+        raise RuntimeError("s") from e
 
     out = torch.tensor([out_tokens], dtype=torch.int64, device=prefix.device)
     if verbose:
@@ -269,7 +269,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
     except Exception as e:
         print(e)
         lib.sd_spec_destroy(sp)
-        raise RuntimeError("s")
+        raise RuntimeError("s") from e
     lib.sd_spec_destroy(sp)
     draft._session.cache_len, target._session.cache_len = draft_len, target_len
     out = torch.tensor([out_tokens], dtype=torch.int64, device=prefix.device)
