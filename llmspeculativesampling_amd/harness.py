@@ -1,13 +1,13 @@
 """Host-side pieces of the reference's evaluation driver that sit either side of the decode path
 (reference evaluation.py).  No model math here: prompt sources, the power-log
-integration and the log lines; ``tools/evaluation.py`` strings them around ``sampling.*``.
+integration and the log lines; ``tools/evaluate_offline.py`` strings them around ``sampling.*``.
 
 * ``read_chatalpaca``   chatalpaca-10k JSONL -> one prompt per assistant turn with the cumulative history
                         (evaluation.py:347-364)
 * ``synthetic_prompts`` the offline stand-in: lengths ~ U{32..512}, seed 5
 * ``ByteTokenizer``     stand-in tokenizer when no local tokenizer directory is given (ids 3.. = bytes, eos 2)
 * ``PowerMonitor`` / ``total_power``   the poller process and the sum over [t1, t2] (evaluation.py:135-152, 418,
-                        471-475), fed by ``tools/gpu_power_monitor.py`` (rocm-smi instead of nvidia-smi)
+                        471-475), fed by ``tools/rocm_power_monitor.py`` (rocm-smi instead of nvidia-smi)
 * ``*_log_lines``       the result lines in the reference's wording (evaluation.py:479-480, 567-583)
 """
 from __future__ import annotations
@@ -78,7 +78,7 @@ class PowerMonitor:
 
     def __init__(self, script: Optional[str] = None):
         here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        self.script = script or os.path.join(here, "tools", "gpu_power_monitor.py")
+        self.script = script or os.path.join(here, "tools", "rocm_power_monitor.py")
         self.proc = None
         self.t1 = self.t2 = 0.0
 

@@ -847,13 +847,13 @@ def test_host_rng_autoregressive_matches_reference_seed(hip):
 
 
 def test_evaluation_driver_runs_offline(tmp_path):
-    """tools/evaluation.py (the reference driver's three loops) end to end on tiny models and
+    """tools/evaluate_offline.py (the reference driver's three loops) end to end on tiny models and
     synthetic prompts: every loop prints its result lines in the reference's wording."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     log = tmp_path / "log.txt"
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluation.py"), "--approx_model_name",
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "evaluate_offline.py"), "--approx_model_name",
                         "tiny-llama-draft", "--target_model_name", "tiny-llama-target", "--n-prompts", "40",
                         "--max_tokens", "8", "--repeats", "1", "--dtype", "float32", "--seed", "7", "--log_file",
                         str(log)], capture_output=True, text=True, timeout=600)

@@ -10,7 +10,7 @@ is a local directory (``--tokenizer``) or a byte-level stand-in; ``--dataset cha
 (chatalpaca-10k.json) and falls back to synthetic prompts with lengths ~ U{32..512}.  ROUGE / exact-match scoring
 (reference utils.py:8-93, hf ``evaluate``) is dataset scoring, not decode, and is not reproduced.
 
-    python tools/evaluation.py --approx_model_name llama-68m --target_model_name llama-2-13b --max_tokens 128 \
+    python tools/evaluate_offline.py --approx_model_name llama-68m --target_model_name llama-2-13b --max_tokens 128 \
         --dataset chatalpaca [--data-path chatalpaca-10k.json --tokenizer /path/to/tokenizer] [--n-prompts 100]
 """
 import argparse
