@@ -38,6 +38,12 @@ struct sd_session {
     float *attn_part;   // [groups*splits <= 64][Hq][TQ][D+2] partial attention sums of the split-key path
     float *part;
     size_t part_floats;
+    // native iteration (sd_spec_*): with want_raw_logits a forward whose lm_head ran unsplit leaves the logits in the
+    // GEMM's own output slab (no copy launch) and says where they are and whether they still have to be rounded to bf16
+    int want_raw_logits;
+    const float *last_logits;
+    long last_logits_ld;
+    int last_logits_round;
     // profiling
     int prof_on;
     std::vector<hipEvent_t> ev_pool;
@@ -302,6 +308,8 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->attn_part = (float *)(s->scratch + p.apart);
     s->part = (float *)(s->scratch + p.part);
     s->part_floats = p.part_floats;
+    s->want_raw_logits = 0;
+    s->last_logits = nullptr;
     s->prof_on = 0;
     s->ev_used = 0;
     s->prof_stream = nullptr;
@@ -512,35 +520,43 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     GemmOut go;
     int rc;
 
-    // ---- embeddings
-    if (llama || ED == H) {
+    // ---- embeddings (+ the first pre-norm in the same launch when there is no input projection)
+    if ((llama || ED == H) && pre) {
         ProfScope ps(s, PC_EMBED, st);
-        hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, H,
-                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, 0);
-        SD_LAUNCH_CHECK();
-    } else {
-        {
-            ProfScope ps(s, PC_EMBED, st);
-            hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, ED,
-                               (const T *)nullptr, 0, eb, 1);
-            SD_LAUNCH_CHECK();
-        }
-        if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
-        ProfScope ps(s, PC_EMBED, st);
-        hipLaunchKernelGGL((reduce_addpos_kernel<T>), dim3(n_new), dim3(256), 0, st, s->part, go.S, go.stride_s, H,
-                           (const T *)m->w.pos_embed, tab, pos_off, x);
-        SD_LAUNCH_CHECK();
-    }
-    // ---- first pre-norm
-    if (pre) {
-        ProfScope ps(s, PC_NORM, st);
-        hipLaunchKernelGGL((norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, H, (const T *)m->n1w[0],
+        hipLaunchKernelGGL((embed_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, tab, (const T *)m->w.embed, H,
+                           llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, (const T *)m->n1w[0],
                            (const T *)m->n1b[0], c.norm_eps, norm_kind, h);
         SD_LAUNCH_CHECK();
     } else {
-        ProfScope ps(s, PC_NORM, st);
-        hipLaunchKernelGGL((to_operand_kernel<T>), dim3(n_new), dim3(256), 0, st, (const T *)x, H, h);
-        SD_LAUNCH_CHECK();
+        if (llama || ED == H) {
+            ProfScope ps(s, PC_EMBED, st);
+            hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, H,
+                               llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, 0);
+            SD_LAUNCH_CHECK();
+        } else {
+            {
+                ProfScope ps(s, PC_EMBED, st);
+                hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, ED,
+                                   (const T *)nullptr, 0, eb, 1);
+                SD_LAUNCH_CHECK();
+            }
+            if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
+            ProfScope ps(s, PC_EMBED, st);
+            hipLaunchKernelGGL((reduce_addpos_kernel<T>), dim3(n_new), dim3(256), 0, st, s->part, go.S, go.stride_s, H,
+                               (const T *)m->w.pos_embed, tab, pos_off, x);
+            SD_LAUNCH_CHECK();
+        }
+        // ---- first pre-norm
+        if (pre) {
+            ProfScope ps(s, PC_NORM, st);
+            hipLaunchKernelGGL((norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, x, H, (const T *)m->n1w[0],
+                               (const T *)m->n1b[0], c.norm_eps, norm_kind, h);
+            SD_LAUNCH_CHECK();
+        } else {
+            ProfScope ps(s, PC_NORM, st);
+            hipLaunchKernelGGL((to_operand_kernel<T>), dim3(n_new), dim3(256), 0, st, (const T *)x, H, h);
+            SD_LAUNCH_CHECK();
+        }
     }
 
     for (int l = 0; l < L; ++l) {
@@ -632,11 +648,16 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             hl = eb;
         }
         if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
-        ProfScope ps(s, PC_LOGITS, st);
-        hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
-                           go.stride_s, c.vocab, c.logits_bf16_round || (!llama && c.dtype == SD_BF16), logits_out,
-                           ld_logits);
-        SD_LAUNCH_CHECK();
+        const int round_t = c.logits_bf16_round || (!llama && c.dtype == SD_BF16);
+        if (s->want_raw_logits && go.S == 1) {
+            s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
+        } else {
+            ProfScope ps(s, PC_LOGITS, st);
+            hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
+                               go.stride_s, c.vocab, round_t, logits_out, ld_logits);
+            SD_LAUNCH_CHECK();
+            s->last_logits = logits_out; s->last_logits_ld = ld_logits; s->last_logits_round = 0;
+        }
     }
     return SD_OK;
 }
@@ -872,13 +893,15 @@ extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld,
                               const float *r, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *out,
                               void *stream);
 
-// feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows
+// feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows, all of them from the
+// final call (a chunk never ends inside the logits rows), so that call's output slab can be handed to the norm as is
 static int feed_rows(sd_session *ses, const int32_t *seq, int from, int upto, int n_logits, float *logits, long ld,
                      void *stream) {
     const int first_logit = upto - n_logits;
     int done = from;
     while (done < upto) {
-        const int m = std::min(ses->max_rows, upto - done);
+        int m = std::min(ses->max_rows, upto - done);
+        if (done < first_logit && done + m > first_logit && done + m < upto) m = first_logit - done;
         const int lo = std::max(first_logit, done);
         const int nl = std::max(0, done + m - lo);
         const int rc = sd_session_forward(ses, seq + done, m, done, nl, nl ? logits + (size_t)(lo - first_logit) * ld : nullptr,
@@ -903,9 +926,12 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     // ---- draft: gamma steps; the sampled token goes straight into seq[] where the next step's embed reads it
     for (int i = 0; i < g; ++i) {
         const int upto = L + i;
-        if ((rc = feed_rows(sp->draft, sp->seq, draft_len, upto, 1, sp->draft_logits, sp->ld_dl, stream)) != SD_OK) return rc;
+        sp->draft->want_raw_logits = 1;
+        rc = feed_rows(sp->draft, sp->seq, draft_len, upto, 1, sp->draft_logits, sp->ld_dl, stream);
+        sp->draft->want_raw_logits = 0;
+        if (rc != SD_OK) return rc;
         draft_len = upto;
-        if ((rc = sd_norm_sample(sp->draft_logits, V, sp->temperature, sp->top_k, sp->top_p, 0,
+        if ((rc = sd_norm_sample(sp->draft->last_logits, V, sp->temperature, sp->top_k, sp->top_p, sp->draft->last_logits_round,
                                  sp->q_hist + (size_t)(upto - 1) * sp->ld, sp->err + i, nullptr, seed_draft,
                                  draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws, stream)) != SD_OK)
             return rc;
@@ -915,8 +941,12 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     {
         const int upto = L + g;
         const int rows = std::min(upto - target_len, g + 1);
-        if ((rc = feed_rows(sp->target, sp->seq, target_len, upto, rows, sp->target_logits, sp->ld_tl, stream)) != SD_OK) return rc;
-        if ((rc = sd_norm_probs(sp->target_logits, rows, V, sp->ld_tl, sp->temperature, sp->top_k, sp->top_p, 0,
+        sp->target->want_raw_logits = 1;
+        rc = feed_rows(sp->target, sp->seq, target_len, upto, rows, sp->target_logits, sp->ld_tl, stream);
+        sp->target->want_raw_logits = 0;
+        if (rc != SD_OK) return rc;
+        if ((rc = sd_norm_probs(sp->target->last_logits, rows, V, sp->target->last_logits_ld, sp->temperature, sp->top_k, sp->top_p,
+                                sp->target->last_logits_round,
                                 sp->p_hist + (size_t)(upto - rows) * sp->ld, sp->ld, sp->err + 2 * g, sp->norm_ws, stream)) != SD_OK)
             return rc;
     }

@@ -499,6 +499,32 @@ __global__ __launch_bounds__(256) void norm_kernel(const T *__restrict__ x, int 
     norm_row<T>(xs, H, w, b, eps, kind, red, h, row);
 }
 
+// Embedding gather + the first pre-norm in one launch (the row is in LDS between the two): x <- embedding (+ OPT
+// positions), h <- norm(x).  Same arithmetic as embed_kernel followed by norm_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_norm_kernel(RowTab tab, const T *__restrict__ table, int H,
+                                                        const T *__restrict__ pos_table, int pos_off,
+                                                        T *__restrict__ x, const T *__restrict__ w,
+                                                        const T *__restrict__ b, float eps, int kind,
+                                                        T *__restrict__ h) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    float *red = xs + H;
+    const int row = blockIdx.x;
+    const int pos = tab_pos(tab, row);
+    const int tok = tab.tok_base[tab_stream(tab, row)][pos];
+    const T *src = table + (size_t)tok * H;
+    const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * H : nullptr;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        float v = to_f(src[i]);
+        if (ps) v = rnd<T>(v + to_f(ps[i]));
+        x[(size_t)row * H + i] = from_f<T>(v);
+        xs[i] = v;
+    }
+    __syncthreads();
+    norm_row<T>(xs, H, w, b, eps, kind, red, h, row);
+}
+
 // x' = rnd(x + rnd(sum part + bias)); then per mode: PRE: x <- x', h <- norm(x');  POST: x,h <- LN(x');
 // NONE: x,h <- x'.   (residual adds: modeling_llama.py:440,446; modeling_opt.py:342-347, 363-368)
 template <typename T> __device__ __forceinline__ void load4(const T *p, float (&o)[4]);
