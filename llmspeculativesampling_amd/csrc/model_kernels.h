@@ -4,6 +4,7 @@
 // reference's per-op result is materialised in the weight dtype.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -696,6 +697,12 @@ template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], 
 }
 
 #define ATT_TQ 8
+#ifdef SD_ATT_STAMPS
+__device__ long long g_att_stamps[16];
+#define ATT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_att_stamps[i] = wall_clock64(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
                                                   T *__restrict__ out, int Hq, int Hkv, int arch,
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     const int kvh = head / (Hq / Hkv);
     const T *karena = (const T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
     const int tid = threadIdx.x;
+    ATT_STAMP(0);
     // long contexts (nsplit > 1, "flash-decoding"): workgroup z takes keys [kb, kb + s_hi) of the group's visible keys and
     // leaves un-normalised partial sums (+ running max and denominator) for attn_combine_kernel; nsplit == 1 is the
     // whole range.  From here on key indices are local to the chunk.
@@ -824,85 +832,136 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
             sc[(size_t)t * s_cap + s] = (s <= vis0 + t) ? v : -INFINITY;
         }
     }
+    ATT_STAMP(1);
     __syncthreads();
+    ATT_STAMP(2);
 
-    {   // softmax in fp32, result rounded to T (modeling_llama.py:371)
-        const int w = tid >> 6, lane = tid & 63;
-        for (int t = w; t < nr; t += 4) {
+    {   // softmax in fp32, result rounded to T (modeling_llama.py:371).  One wave per row; with more than 4 rows one
+        // half-wave per row (a 5-row verify group is then one pass instead of two).  The half-wave keeps the two partial
+        // sums a full wave's lower and upper lanes would hold and reduces them with the same butterflies, so a row's
+        // result does not depend on which form ran (rows of different group sizes stay bit-identical).
+        const bool half = nr > 4;
+        const int lane = half ? (tid & 31) : (tid & 63), grp = half ? tid >> 5 : tid >> 6, ngrp = half ? 8 : 4;
+        auto bfly_max = [&](float v) {
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+            return v;
+        };
+        auto bfly_sum = [&](float v) {
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            return v;
+        };
+        for (int t = grp; t < nr; t += ngrp) {
             float *row = sc + (size_t)t * s_cap;
             const int len = max(0, min(s_hi, vis0 + t + 1));
-            float m = -INFINITY;
-            for (int s = lane; s < len; s += 64) m = fmaxf(m, row[s]);
-            m = wave_max(m);
-            float sum = 0.f;
-            for (int s = lane; s < len; s += 64) {
-                const float e = expf(row[s] - m);
-                row[s] = e;
-                sum += e;
+            float m, sum;
+            if (half) {
+                float m0 = -INFINITY;
+                for (int s = lane; s < len; s += 32) m0 = fmaxf(m0, row[s]);
+                m = bfly_max(m0);
+                float s0 = 0.f, s1 = 0.f;                         // what lanes l and l + 32 of a full wave accumulate
+                for (int s = lane; s < len; s += 64) {
+                    const float e = expf(row[s] - m);
+                    row[s] = e;
+                    s0 += e;
+                }
+                for (int s = lane + 32; s < len; s += 64) {
+                    const float e = expf(row[s] - m);
+                    row[s] = e;
+                    s1 += e;
+                }
+                sum = bfly_sum(s0) + bfly_sum(s1);
+            } else {
+                float m0 = -INFINITY;
+                for (int s = lane; s < len; s += 64) m0 = fmaxf(m0, row[s]);
+                m0 = bfly_max(m0);
+                m = fmaxf(m0, __shfl_xor(m0, 32, 64));
+                float s0 = 0.f;
+                for (int s = lane; s < len; s += 64) {
+                    const float e = expf(row[s] - m);
+                    row[s] = e;
+                    s0 += e;
+                }
+                s0 = bfly_sum(s0);
+                const float so = __shfl_xor(s0, 32, 64);
+                sum = lane < 32 ? s0 + so : so + s0;              // lower-half sum first, on every lane
             }
-            sum = wave_sum(sum);
+            const int LW = half ? 32 : 64;
             if (nsplit > 1) {                                     // keep exp(score - local max); the combine normalises
-                for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? row[s] : 0.f;
+                for (int s = lane; s < s_hi; s += LW) row[s] = s < len ? row[s] : 0.f;
                 if (lane == 0) { ml[t][0] = m; ml[t][1] = sum; }
             } else {
-                for (int s = lane; s < s_hi; s += 64) row[s] = s < len ? rnd<T>(row[s] / sum) : 0.f;
+                for (int s = lane; s < s_hi; s += LW) row[s] = s < len ? rnd<T>(row[s] / sum) : 0.f;
             }
         }
     }
+    ATT_STAMP(3);
     __syncthreads();
+    ATT_STAMP(4);
 
     {
         // P.V: 16-byte V loads, LPR lanes across one key row, the other lanes of the wave on other keys; keys
         // striped over all thread groups; partial sums folded inside the wave by shuffles, then across the 4
-        // waves through LDS.
-        constexpr int LPR = D / 8, GPW = 64 / LPR, NGRP = 256 / LPR;
+        // waves through LDS.  Instantiated for 1, 3, 5 and ATT_TQ rows so that a decode step (1 row) or a verify
+        // group (gamma + 1 rows) does not multiply rows it does not have (1 row: P.V 3.5 -> 1.2 us); per-row
+        // arithmetic is the same in all of them.
+        constexpr int LPR = D / 8, NGRP = 256 / LPR;
         const int dp = tid % LPR, sg = tid / LPR;
-        float a[ATT_TQ][8];
+        auto pv = [&](auto nrows) {
+            constexpr int NR = decltype(nrows)::value;
+            float a[NR][8];
 #pragma unroll
-        for (int t = 0; t < ATT_TQ; ++t)
+            for (int t = 0; t < NR; ++t)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[t][j] = 0.f;
+                for (int j = 0; j < 8; ++j) a[t][j] = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < VPF; ++jj) {
-            const int s = sg + jj * NGRP;
-            if (s < s_hi) {
+            for (int jj = 0; jj < VPF; ++jj) {
+                const int s = sg + jj * NGRP;
+                if (s < s_hi) {
+                    float v[8];
+                    unpack8<T>(vpre[jj], v);
+#pragma unroll
+                    for (int t = 0; t < NR; ++t) {
+                        const float p = sc[(size_t)t * s_cap + s];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
+                    }
+                }
+            }
+#pragma unroll 4
+            for (int s = sg + VPF * NGRP; s < s_hi; s += NGRP) {
                 float v[8];
-                unpack8<T>(vpre[jj], v);
+                load8(Vv + (size_t)s * D + dp * 8, v);
 #pragma unroll
-                for (int t = 0; t < ATT_TQ; ++t) {
+                for (int t = 0; t < NR; ++t) {
                     const float p = sc[(size_t)t * s_cap + s];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
                 }
             }
-        }
-#pragma unroll 4
-        for (int s = sg + VPF * NGRP; s < s_hi; s += NGRP) {
-            float v[8];
-            load8(Vv + (size_t)s * D + dp * 8, v);
 #pragma unroll
-            for (int t = 0; t < ATT_TQ; ++t) {
-                const float p = sc[(size_t)t * s_cap + s];
+            for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
+                for (int t = 0; t < NR; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[t][j] += __shfl_xor(a[t][j], off, 64);
+            const int w = tid >> 6, lane = tid & 63;
+            if (lane < LPR) {
+#pragma unroll
+                for (int t = 0; t < NR; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) red[((size_t)w * ATT_TQ + t) * D + lane * 8 + j] = a[t][j];
             }
-        }
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1)
-#pragma unroll
-            for (int t = 0; t < ATT_TQ; ++t)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[t][j] += __shfl_xor(a[t][j], off, 64);
-        const int w = tid >> 6, lane = tid & 63;
-        if (lane < LPR) {
-#pragma unroll
-            for (int t = 0; t < ATT_TQ; ++t)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) red[((size_t)w * ATT_TQ + t) * D + lane * 8 + j] = a[t][j];
-        }
-        (void)GPW;
+        };
+        if (nr == 1) pv(std::integral_constant<int, 1>{});
+        else if (nr <= 3) pv(std::integral_constant<int, 3>{});           // gamma = 2
+        else if (nr <= 5) pv(std::integral_constant<int, 5>{});           // gamma = 4, the harness default
+        else pv(std::integral_constant<int, ATT_TQ>{});
     }
+    ATT_STAMP(5);
     __syncthreads();
+    ATT_STAMP(6);
     if (nsplit > 1) {
         float *pz = partial + (((size_t)blockIdx.y * Hq + head) * nsplit + blockIdx.z) * ATT_TQ * (D + 2);
         for (int i = tid; i < nr * D; i += 256) {
@@ -922,6 +981,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
         out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(a);
     }
+    ATT_STAMP(7);
 }
 
 // out = sum_z acc_z * exp(m_z - M) / sum_z l_z * exp(m_z - M): merges the nsplit key chunks of one (head, group)
