@@ -733,10 +733,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     __shared__ float ml[ATT_TQ][2];
 
     // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
-    // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128)
+    // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128).  On the MFMA
+    // path they go out right AFTER the first batch of K tiles, which is what the first phase waits for.
     constexpr int LPR_ = D / 8, NGRP_ = 256 / LPR_, VPF = 16;
     u32x4 vpre[VPF][sizeof(T) == 2 ? 1 : 2];
-    {
+    auto issue_v = [&]() {
         const int dp = tid % LPR_, sg = tid / LPR_;
 #pragma unroll
         for (int j = 0; j < VPF; ++j) {
@@ -747,7 +748,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
             }
         }
-    }
+    };
+    if constexpr (!(sizeof(T) == 2 && D >= 32)) issue_v();
     if constexpr (!(sizeof(T) == 2 && D >= 32)) {                 // the MFMA path reads q straight into registers
         for (int i = tid; i < ATT_TQ * D; i += 256) {
             const int t = i / D, d = i - t * D;
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                                : u32x4{0u, 0u, 0u, 0u};
         // key tiles are taken 4 at a time per wave with all of their K loads issued before the first MFMA
         // (a plain loop over tiles would pay one memory round trip per tile)
+        bool v_issued = false;
         for (int kt0 = w; kt0 * 16 < s_hi; kt0 += 16) {
             u32x4 kf[4][D / 32];
 #pragma unroll
@@ -779,6 +782,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                     for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
                 }
             }
+            if (!v_issued) { issue_v(); v_issued = true; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kt = kt0 + 4 * u;
@@ -801,6 +805,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 }
             }
         }
+        if (!v_issued) issue_v();                                 // a wave without a key tile of its own
     } else
     for (int s = tid; s < s_hi; s += 256) {
         float acc[ATT_TQ];
