@@ -40,15 +40,32 @@ template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (
 template <typename T> __device__ __forceinline__ float rnd(float x) { return to_f(from_f<T>(x)); }
 
 // ---- wave / block reductions (wave = 64 lanes)
+// Data-parallel-primitive moves instead of __shfl_xor (which hipcc lowers to six dependent ds_bpermute_b32 through the
+// LDS crossbar, ~0.3 us per reduction): xor 1, xor 2, half-row mirror, row mirror leave every lane with its row's
+// (16 lanes) result; row_bcast15 / row_bcast31 carry it across the four rows into lanes 48..63; lane 63 is read back.
+// The order of the additions is fixed, so results stay bit-reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1, 0xF>(v, 0.f);        // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF>(v, 0.f);        // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF>(v, 0.f);       // row_half_mirror
+    v += dpp_mov<0x140, 0xF>(v, 0.f);       // row_mirror
+    v += dpp_mov<0x142, 0xA>(v, 0.f);       // row_bcast15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xC>(v, 0.f);       // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

@@ -548,12 +548,19 @@ template <> __device__ __forceinline__ void store4t<bf16_t>(bf16_t *p, const flo
 // (split-K slabs, residual, bias, norm weights) are issued up front, and the only block-wide step is the reduction of
 // the statistics.  No LDS row buffer.
 #define RN_RG 2
+#ifdef SD_RN_STAMPS
+__device__ long long g_rn_stamps[8];
+#define RN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_rn_stamps[i] = wall_clock64(); } while (0)
+#else
+#define RN_STAMP(i) do { } while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, const float *__restrict__ part, int S,
                                                             size_t stride_s, int H, const T *__restrict__ bias,
                                                             const T *__restrict__ w, const T *__restrict__ b,
                                                             float eps, int kind, int mode, T *__restrict__ h) {
     __shared__ float red[32];
+    RN_STAMP(0);
     const int row = blockIdx.x;
     T *xr = x + (size_t)row * H;                                  // residual stream: plain rows; h: GEMM operand layout
     float v[RN_RG][4], wv[RN_RG][4], bv[RN_RG][4];
@@ -574,6 +581,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
             }
         }
     }
+    RN_STAMP(1);
     float a = 0.f, a2 = 0.f;
 #pragma unroll
     for (int g = 0; g < RN_RG; ++g) {
@@ -590,6 +598,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
         if (mode != RES_POST) store4t<T>(xr + i, v[g]);
         if (mode == RES_NONE) store4t<T>(h + xoff<T>(row, i, H), v[g]);
     }
+    RN_STAMP(2);
     if (mode == RES_NONE) return;
     float mean = 0.f, r;
     if (kind == NORM_RMS) {
@@ -604,6 +613,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
                 for (int j = 0; j < 4; ++j) { const float d = v[g][j] - mean; d2 += d * d; }
         r = 1.0f / sqrtf(block_sum(d2, red) / (float)H + eps);
     }
+    RN_STAMP(3);
 #pragma unroll
     for (int g = 0; g < RN_RG; ++g) {
         if (!on[g]) continue;
@@ -616,6 +626,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
         store4t<T>(h + xoff<T>(row, i, H), o);
         if (mode == RES_POST) store4t<T>(xr + i, o);
     }
+    RN_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
