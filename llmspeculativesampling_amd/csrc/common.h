@@ -67,6 +67,26 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_mov<0x143, 0xC>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Sums / maxima over the two 32-lane halves of a wave (lanes 0-31 -> lo, 32-63 -> hi), every lane gets both.
+// lo and hi are each "second row + first row" of their half; an inactive half yields an unspecified value.
+__device__ __forceinline__ void half_sums(float v, float &lo, float &hi) {
+    v += dpp_mov<0xB1, 0xF>(v, 0.f);
+    v += dpp_mov<0x4E, 0xF>(v, 0.f);
+    v += dpp_mov<0x141, 0xF>(v, 0.f);
+    v += dpp_mov<0x140, 0xF>(v, 0.f);
+    v += dpp_mov<0x142, 0xA>(v, 0.f);
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ void half_maxes(float v, float &lo, float &hi) {
+    v = fmaxf(v, dpp_mov<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xA>(v, v));
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

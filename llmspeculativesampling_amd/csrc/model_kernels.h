@@ -854,28 +854,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
 
     {   // softmax in fp32, result rounded to T (modeling_llama.py:371).  One wave per row; with more than 4 rows one
         // half-wave per row (a 5-row verify group is then one pass instead of two).  The half-wave keeps the two partial
-        // sums a full wave's lower and upper lanes would hold and reduces them with the same butterflies, so a row's
-        // result does not depend on which form ran (rows of different group sizes stay bit-identical).
+        // sums a full wave's lower and upper lanes would hold and reduces them with the same DPP steps (half_sums), so a
+        // row's result does not depend on which form ran (rows of different group sizes stay bit-identical).
         const bool half = nr > 4;
         const int lane = half ? (tid & 31) : (tid & 63), grp = half ? tid >> 5 : tid >> 6, ngrp = half ? 8 : 4;
-        auto bfly_max = [&](float v) {
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-            return v;
-        };
-        auto bfly_sum = [&](float v) {
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            return v;
-        };
+        const bool upper = (tid & 32) != 0;
         for (int t = grp; t < nr; t += ngrp) {
             float *row = sc + (size_t)t * s_cap;
             const int len = max(0, min(s_hi, vis0 + t + 1));
-            float m, sum;
+            float m, sum, lo, hi;
             if (half) {
                 float m0 = -INFINITY;
                 for (int s = lane; s < len; s += 32) m0 = fmaxf(m0, row[s]);
-                m = bfly_max(m0);
+                half_maxes(m0, lo, hi);
+                m = upper ? hi : lo;
                 float s0 = 0.f, s1 = 0.f;                         // what lanes l and l + 32 of a full wave accumulate
                 for (int s = lane; s < len; s += 64) {
                     const float e = expf(row[s] - m);
@@ -887,21 +879,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                     row[s] = e;
                     s1 += e;
                 }
-                sum = bfly_sum(s0) + bfly_sum(s1);
+                float lo1, hi1;
+                half_sums(s0, lo, hi);
+                half_sums(s1, lo1, hi1);
+                sum = upper ? hi + hi1 : lo + lo1;
             } else {
                 float m0 = -INFINITY;
                 for (int s = lane; s < len; s += 64) m0 = fmaxf(m0, row[s]);
-                m0 = bfly_max(m0);
-                m = fmaxf(m0, __shfl_xor(m0, 32, 64));
+                half_maxes(m0, lo, hi);
+                m = fmaxf(lo, hi);
                 float s0 = 0.f;
                 for (int s = lane; s < len; s += 64) {
                     const float e = expf(row[s] - m);
                     row[s] = e;
                     s0 += e;
                 }
-                s0 = bfly_sum(s0);
-                const float so = __shfl_xor(s0, 32, 64);
-                sum = lane < 32 ? s0 + so : so + s0;              // lower-half sum first, on every lane
+                half_sums(s0, lo, hi);
+                sum = lo + hi;                                    // lanes 0-31 first, then 32-63: the half-wave form's order
             }
             const int LW = half ? 32 : 64;
             if (nsplit > 1) {                                     // keep exp(score - local max); the combine normalises
