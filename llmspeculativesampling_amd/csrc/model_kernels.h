@@ -859,10 +859,51 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         const bool half = nr > 4;
         const int lane = half ? (tid & 31) : (tid & 63), grp = half ? tid >> 5 : tid >> 6, ngrp = half ? 8 : 4;
         const bool upper = (tid & 32) != 0;
+        const int LW = half ? 32 : 64;
+        constexpr int SREG = 8;                                   // scores a lane keeps in registers (short contexts)
+        const bool in_regs = s_hi <= SREG * LW;
         for (int t = grp; t < nr; t += ngrp) {
             float *row = sc + (size_t)t * s_cap;
             const int len = max(0, min(s_hi, vis0 + t + 1));
             float m, sum, lo, hi;
+            if (in_regs) {
+                // one LDS read and one LDS write per score: the row stays in registers between the three passes.  Each
+                // lane owns the keys lane + k*LW; a half-wave lane thereby alternates between the keys that lanes l and
+                // l + 32 of a full wave own, and adds them into the same two partial sums as the loops below.
+                float v[SREG];
+#pragma unroll
+                for (int k = 0; k < SREG; ++k) { const int s = lane + k * LW; v[k] = s < len ? row[s] : -INFINITY; }
+                float m0 = v[0];
+#pragma unroll
+                for (int k = 1; k < SREG; ++k) m0 = fmaxf(m0, v[k]);
+                half_maxes(m0, lo, hi);
+                m = half ? (upper ? hi : lo) : fmaxf(lo, hi);
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < SREG; ++k) {
+                    const int s = lane + k * LW;
+                    if (s < len) {
+                        v[k] = expf(v[k] - m);
+                        if (half && (k & 1)) s1 += v[k]; else s0 += v[k];
+                    } else v[k] = 0.f;
+                }
+                if (half) {
+                    float lo1, hi1;
+                    half_sums(s0, lo, hi);
+                    half_sums(s1, lo1, hi1);
+                    sum = upper ? hi + hi1 : lo + lo1;
+                } else {
+                    half_sums(s0, lo, hi);
+                    sum = lo + hi;
+                }
+#pragma unroll
+                for (int k = 0; k < SREG; ++k) {
+                    const int s = lane + k * LW;
+                    if (s < s_hi) row[s] = nsplit > 1 ? v[k] : (s < len ? rnd<T>(v[k] / sum) : 0.f);
+                }
+                if (nsplit > 1 && lane == 0) { ml[t][0] = m; ml[t][1] = sum; }
+                continue;
+            }
             if (half) {
                 float m0 = -INFINITY;
                 for (int s = lane; s < len; s += 32) m0 = fmaxf(m0, row[s]);
@@ -897,7 +938,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 half_sums(s0, lo, hi);
                 sum = lo + hi;                                    // lanes 0-31 first, then 32-63: the half-wave form's order
             }
-            const int LW = half ? 32 : 64;
             if (nsplit > 1) {                                     // keep exp(score - local max); the combine normalises
                 for (int s = lane; s < s_hi; s += LW) row[s] = s < len ? row[s] : 0.f;
                 if (lane == 0) { ml[t][0] = m; ml[t][1] = sum; }
