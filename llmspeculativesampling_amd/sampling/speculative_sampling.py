@@ -216,6 +216,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
     draft_len = target_len = 0
     res_view = res_host.numpy()
     dms, tms = C.c_float(0), C.c_float(0)
+    eos_total = ori_eos_cnt
     try:
         while len(host_seq) < T:
             tick = process_time_ns()
@@ -250,11 +251,12 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                 acc_rate.append(min(1.0, float(res.p_at[i]) / float(res.q_at[i])))
             acc_len.append(l)
             assert n >= L - 1, f"n {n}, prefix_len {L}"
-            host_seq = host_seq + tok_host[:l].tolist() + [t]
+            new_toks = tok_host[:l].tolist() + [t]
+            host_seq = host_seq + new_toks
             draft_len = min(L + gamma - 1, n + 1)        # rollback(n+1) of both caches (:2000, :2015/2023)
             target_len = n + 1
             out_tokens = host_seq
-            eos_total = sum(1 for x in host_seq if x == eos_token_id)
+            eos_total += sum(1 for x in new_toks if x == eos_token_id)      # running count: the loop stays O(new tokens)
             if eos_total > ori_eos_cnt:
                 seen, cut = 0, len(host_seq)
                 for idx, x in enumerate(host_seq):
