@@ -471,7 +471,7 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
     auto lds_for = [&](int nsplit, int *s_cap) {
         const int keys = nsplit > 1 ? (((s_max + nsplit - 1) / nsplit + 15) & ~15) : s_max;
         *s_cap = (int)align_up(keys, 64);
-        return sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * *s_cap);
+        return sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * *s_cap);
     };
     static const int split_keys = getenv("SD_ATTN_SPLIT_KEYS") ? atoi(getenv("SD_ATTN_SPLIT_KEYS")) : ATT_SPLIT_KEYS;
     static const int keys_per = getenv("SD_ATTN_KEYS_PER_SPLIT") ? atoi(getenv("SD_ATTN_KEYS_PER_SPLIT")) : 256;

@@ -720,8 +720,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                                                   float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
-    float *red = qs + ATT_TQ * D;                                 // [4 waves][TQ][D]
-    float *sc = red + 4 * ATT_TQ * D;                             // [TQ][s_cap]
+    constexpr int ATT_RG = 256 / (D / 8);                         // key groups of the P.V phase, each leaves a partial sum
+    float *red = qs + ATT_TQ * D;                                 // [ATT_RG][TQ][D]
+    float *sc = red + ATT_RG * ATT_TQ * D;                        // [TQ][s_cap]
     // one group = up to ATT_TQ consecutive rows of one stream; "pos0 + r0" below is the position of its first row
     const int head = blockIdx.x, r0 = tab.grp_row0[blockIdx.y];
     const int nr = tab.grp_n[blockIdx.y];
@@ -990,19 +991,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                     for (int j = 0; j < 8; ++j) a[t][j] = fmaf(p, v[j], a[t][j]);
                 }
             }
+            // every key group's partial sums go to LDS as they are; the epilogue adds the 256 / LPR of them (folding
+            // inside the wave first took ~80 ds_bpermute shuffles per thread)
 #pragma unroll
-            for (int off = LPR; off < 64; off <<= 1)
+            for (int t = 0; t < NR; ++t)
 #pragma unroll
-                for (int t = 0; t < NR; ++t)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) a[t][j] += __shfl_xor(a[t][j], off, 64);
-            const int w = tid >> 6, lane = tid & 63;
-            if (lane < LPR) {
-#pragma unroll
-                for (int t = 0; t < NR; ++t)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) red[((size_t)w * ATT_TQ + t) * D + lane * 8 + j] = a[t][j];
-            }
+                for (int j = 0; j < 8; ++j) red[((size_t)sg * ATT_TQ + t) * D + dp * 8 + j] = a[t][j];
         };
         if (nr == 1) pv(std::integral_constant<int, 1>{});
         else if (nr <= 3) pv(std::integral_constant<int, 3>{});           // gamma = 2
@@ -1018,7 +1012,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
             const int t = i / D, d = i - t * D;
             float a = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+            for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
             pz[(size_t)t * (D + 2) + d] = a;
         }
         if (tid < nr) { pz[(size_t)tid * (D + 2) + D] = ml[tid][0]; pz[(size_t)tid * (D + 2) + D + 1] = ml[tid][1]; }
@@ -1028,7 +1022,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         const int t = i / D, d = i - t * D;
         float a = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+        for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
         out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(a);
     }
     ATT_STAMP(7);

@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < rows; ++i) { tab.row_pos[i] = ctx + i; tab.row_stream[i] = 0; }
     tab.grp_row0[0] = 0; tab.grp_n[0] = rows; tab.grp_pos[0] = ctx; tab.grp_stream[0] = 0;
     const int s_max = ctx + rows, s_cap = (s_max + 63) / 64 * 64;
-    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)4 * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
     hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<bf16_t, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 5; ++it) {
