@@ -289,7 +289,8 @@ int sd_spec_create(sd_session *draft, sd_session *target, int gamma, float tempe
 int sd_spec_destroy(sd_spec *sp);
 int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_t seed_draft, uint64_t draw_draft0,
                       uint64_t seed_accept, uint64_t draw_scan0, uint64_t draw_resample, const float *r_const,
-                      sd_accept_result *res_host, int32_t *tok_host, void *stream);
+                      sd_accept_result *res_host, int32_t *tok_host /* gamma+2 ids from seq[L], may be NULL */,
+                      void *stream);
 /* HIP-event timing of the draft phase and the target (verify) phase of the last iteration, on the launch stream. */
 int sd_spec_timing(sd_spec *sp, int on);
 int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms);

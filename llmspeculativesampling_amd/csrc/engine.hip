@@ -916,7 +916,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
                                  uint64_t draw_draft0, uint64_t seed_accept, uint64_t draw_scan0,
                                  uint64_t draw_resample, const float *r_const, sd_accept_result *res_host,
                                  int32_t *tok_host, void *stream) {
-    SD_REQUIRE(sp && res_host && tok_host, "sd_spec_iteration: null argument");
+    SD_REQUIRE(sp && res_host, "sd_spec_iteration: null argument");
     SD_REQUIRE(L >= 1 && draft_len >= 0 && draft_len < L && target_len >= 0 && target_len < L + sp->gamma,
                "sd_spec_iteration: L=%d draft_len=%d target_len=%d", L, draft_len, target_len);
     hipStream_t st = (hipStream_t)stream;
@@ -958,6 +958,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
                                       sp->err, 3 * g + 1, st)) != SD_OK)
         return rc;
     SD_HIP_CHECK(hipMemcpyAsync(res_host, sp->res_dev, sizeof(sd_accept_result), hipMemcpyDeviceToHost, st));
-    SD_HIP_CHECK(hipMemcpyAsync(tok_host, sp->seq + L, sizeof(int32_t) * (size_t)(g + 2), hipMemcpyDeviceToHost, st));
+    if (tok_host)       // optional second copy; the result block already carries the drafted tokens and the next one
+        SD_HIP_CHECK(hipMemcpyAsync(tok_host, sp->seq + L, sizeof(int32_t) * (size_t)(g + 2), hipMemcpyDeviceToHost, st));
     return SD_OK;
 }

@@ -232,7 +232,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
             d_res = noise.next_draws(1)
             check(lib.sd_spec_iteration(sp, L, draft_len, target_len, seed_draft, d_draft, noise.seed, d_scan, d_res,
                                         r_const.data_ptr() if r_const is not None else None, res_host.data_ptr(),
-                                        tok_host.data_ptr(), st), "sd_spec_iteration")
+                                        None, st), "sd_spec_iteration")
             stream_obj.synchronize()
             res = SdAcceptResult.from_buffer_copy(res_view.tobytes())
             if res.flags & 2:
@@ -251,7 +251,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                 acc_rate.append(min(1.0, float(res.p_at[i]) / float(res.q_at[i])))
             acc_len.append(l)
             assert n >= L - 1, f"n {n}, prefix_len {L}"
-            new_toks = tok_host[:l].tolist() + [t]
+            new_toks = [int(res.drafted[i]) for i in range(l)] + [t]      # the result block carries the drafted ids
             host_seq = host_seq + new_toks
             draft_len = min(L + gamma - 1, n + 1)        # rollback(n+1) of both caches (:2000, :2015/2023)
             target_len = n + 1
