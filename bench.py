@@ -2,7 +2,7 @@
 """Headline benchmark: accepted tokens/sec + mean accept-len of speculative_sampling,
 llama-68m -> Llama-2-13b, gamma = 4, bf16, prompt 128, max_len 128 (BASELINE.json configs[1]).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: this process spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,12 +10,16 @@ One step = one speculative_sampling() call over one prompt stream (SURVEY.md 8(d
 stream s has prompt seed 1000+s and RNG seed 2000+s).  Streams are independent, so ranks shard them
 with no collective on the data path; one all_gather of token ids at the end of the timed region
 (SURVEY.md 8(e)).  Weights are random-init from the committed config JSONs (no checkpoints offline), so the
-accept length is ~0 by construction and `value` is essentially 1 token per draft+verify iteration;
-`mean_accept_len` is reported next to it.  Rank 0 prints ONE JSON line.
+accept length of the headline pair is ~0 by construction and `value` is essentially 1 token per draft+verify
+iteration; `mean_accept_len` is reported next to it, and `acceptance_sweep` repeats the same workload on a
+synthetic pair of the same two architectures whose distributions are correlated by a knob (synth.py, "Acceptance
+dial"), so that partial accepts, the all-accept branch and the bonus sample are timed too.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +33,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -51,7 +55,79 @@ def parse():
                     help="throughput mode (SURVEY 8(f)): this many prompt streams decode in lockstep per step and share every "
                          "weight pass (speculative_sampling_batch); 1 = the single-stream path of BASELINE configs[1]")
     ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
-    return ap.parse_args()
+    ap.add_argument("--accept-sweep", type=int, default=1,
+                    help="after the headline, time the same workload on the acceptance-dial pair at each --sweep-sigmas (N=1)")
+    ap.add_argument("--sweep-sigmas", default="0,0.04,0.08,0.16,0.32")
+    ap.add_argument("--sweep-steps", type=int, default=2)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (fresh interpreters, one per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, and wait for them.  Rank 0 prints the
+    JSON line; the exit code is non-zero if any rank failed."""
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0:
+                rc = rc or code
+                print(f"[bench] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                for q in alive:                      # a dead rank would leave the others in a collective forever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def stub_worker(args, rank, world):
+    """SPECDEC_BENCH_STUB=1 (CPU tests of the launcher): the real protocol - barrier, K timed steps, the gather of
+    the generated ids, max-over-ranks time, one JSON line from rank 0 - over gloo with a fake decode step."""
+    import torch.distributed as dist
+    from llmspeculativesampling_amd.dist import gather_streams
+    if os.environ.get("SPECDEC_BENCH_STUB_FAIL_RANK") == str(rank):
+        return 3                                     # launcher test: a rank that dies before the rendezvous
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.time()
+    outs, new_tokens = [], 0
+    for i in range(args.steps):
+        s = rank + i * world
+        outs.append(torch.arange(args.prompt_len + args.max_len, dtype=torch.int64)[None] + s)
+        new_tokens += args.max_len
+    width = args.prompt_len + args.max_len + args.gamma + 1
+    if world > 1:
+        streams = gather_streams(outs, args.steps * world, width, device="cpu")
+        assert [int(x[0]) for x in streams] == list(range(args.steps * world))
+        dist.barrier()
+    stats = torch.tensor([time.time() - t0, float(new_tokens)], dtype=torch.float64)
+    if world > 1:
+        tmax, tot = stats[:1].clone(), stats[1:].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        stats = torch.cat([tmax, tot])
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": float(stats[1]) / max(float(stats[0]), 1e-9), "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "new_tokens": float(stats[1]),
+                          "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def algorithmic_verify_bytes(cfg, gamma, S, wbytes=2, kvbytes=2):
@@ -147,20 +223,80 @@ def cpu_baseline(args, dcfg, tcfg, dm, tm):
                    f"prompt {args.cpu_prompt_len}, max_len {r['n_tok']} (the GPU run uses max_len {args.max_len}), gamma "
                    f"{args.gamma}: {r['new']} tokens in {r['wall']:.1f} s wall / {r['cpu']:.1f} s process_time over "
                    f"{r['iters']} iterations incl. both prefills; {per_iter_txt}weight copy {t_copy:.1f} s not timed"),
-        "wall_s": r["wall"], "process_time_s": r["cpu"], "iterations": r["iters"],
+        "wall_s": r["wall"], "process_time_s": r["cpu"], "iterations": r["iters"], "max_len": r["n_tok"],
         "s_per_iteration": r["per_iter"],
         "mean_accept_len": float(np.mean(r["acc"])) if r["acc"] else 0.0,
     }
 
 
-def main():
-    args = parse()
+def acceptance_sweep(args, dcfg, tcfg, max_pos):
+    """The headline workload (same architectures, shapes, prompt length, max_len, gamma, sampling parameters, native
+    device-RNG loop) on the acceptance-dial pair: one 13b-shaped target, one 68m-shaped draft per sigma.  Reports
+    accepted tokens/s and the mean accept length per point; the all-accept branch (rollback(n+2), 2-row draft step,
+    bonus sample) and partial accepts are inside these timed regions."""
+    from llmspeculativesampling_amd.engine import SpecDecModel
+    from llmspeculativesampling_amd.noise import DeviceNoise
+    from llmspeculativesampling_amd.sampling import speculative_sampling
+    from llmspeculativesampling_amd.synth import dial_draft_transform, dial_target_transform
+    base = SpecDecModel.synthetic(dcfg, seed=11, dtype=torch.bfloat16, max_pos=max_pos, transform=dial_draft_transform(0.0, 11))
+    tgt = SpecDecModel.synthetic(tcfg, seed=12, dtype=torch.bfloat16, max_pos=max_pos,
+                                 transform=dial_target_transform(base._synth_get, dcfg.hidden_size, tcfg.hidden_size))
+    points = []
+    for sg in [float(x) for x in args.sweep_sigmas.split(",") if x.strip() != ""]:
+        drf = base if sg == 0.0 else SpecDecModel.synthetic(dcfg, seed=11, dtype=torch.bfloat16, max_pos=max_pos,
+                                                            transform=dial_draft_transform(sg, 11))
+        tot_new = tot_acc = tot_it = 0
+        logs = {"draft_ms": [], "target": []}
+        t_el = 0.0
+        for i in range(1 + args.sweep_steps):                 # first call = warmup
+            prompt = prompt_for(500 + i, tcfg.vocab_size, args.prompt_len).cuda()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out, d = speculative_sampling(prompt, drf, tgt, eos_token_id=-1, pad_token_id=None, max_len=args.max_len,
+                                          gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True,
+                                          rng=DeviceNoise(seed=3000 + i), _event_logs=logs if i else None)
+            torch.cuda.synchronize()
+            if i:
+                t_el += time.time() - t0
+                tot_new += int(out.shape[1]) - args.prompt_len
+                tot_acc += int(sum(d["acc_len"]))
+                tot_it += int(d["target_call_times"])
+        ver = [ms for (ms, n_new, _) in logs["target"] if n_new <= args.gamma + 1]
+        points.append({"sigma": sg, "value": tot_new / t_el, "unit": "tokens/s", "mean_accept_len": tot_acc / max(1, tot_it),
+                       "iterations": tot_it, "new_tokens": tot_new, "ms_per_iteration": t_el / max(1, tot_it) * 1e3,
+                       "verify_avg_ms": float(np.mean(ver)) if ver else None,
+                       "draft_phase_avg_ms": float(np.mean([m for m in logs["draft_ms"] if m < 50.0])) if logs["draft_ms"] else None})
+        if drf is not base:
+            del drf
+    del tgt, base
+    torch.cuda.empty_cache()
+    return {"pair": "acceptance-dial pair (synth.py): llama-68m-shaped draft with sigma * noise on its lm_head, "
+                    "Llama-2-13b-shaped target carrying the sigma=0 draft's embedding / head in its first 768 hidden dims; "
+                    "all weights dense random tensors, all 25.7 GB streamed per verify",
+            "steps_per_point": args.sweep_steps, "eos": "disabled (eos_token_id=-1) so every point decodes max_len tokens",
+            "points": points}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    # N > 1 without a launcher's environment: this process becomes the launcher (no GPU call before or in it)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled n_gpus", file=sys.stderr)
+        return 2
+    if os.environ.get("SPECDEC_BENCH_STUB"):
+        return stub_worker(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # rehearsal on a one-GPU box: SPECDEC_DIST_BACKEND=gloo puts every rank on cuda:0 and the collectives on the host
     backend = os.environ.get("SPECDEC_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        print(f"[bench] {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local if backend == "nccl" else 0)
     comm_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
@@ -335,18 +471,46 @@ def main():
         "roofline": roofline, "model_build_s": t_build,
     }
 
+    if args.accept_sweep and rank == 0 and world == 1 and BS == 1 and dcfg.arch == "llama" and tcfg.arch == "llama":
+        try:
+            result["acceptance_sweep"] = acceptance_sweep(args, dcfg, tcfg, max_pos)
+        except Exception as e:
+            result["acceptance_sweep"] = {"error": f"{type(e).__name__}: {e}"}
+
     if args.cpu_baseline and rank == 0 and world == 1:
         try:
-            result["cpu_baseline"] = cpu_baseline(args, dcfg, tcfg, dm, tm)
+            cb = cpu_baseline(args, dcfg, tcfg, dm, tm)
+            # the same bounded workload (same prompt, same max_len) on the GPU, so the two numbers are on one workload
+            n_tok = int(cb.get("max_len", args.cpu_max_len))
+            prompt = prompt_for(0, tcfg.vocab_size, args.cpu_prompt_len).cuda()
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                w0 = time.time()
+                out, d = speculative_sampling(prompt, dm, tm, eos_token_id=2, pad_token_id=None, max_len=n_tok,
+                                              gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True,
+                                              rng=DeviceNoise(seed=2000))
+                torch.cuda.synchronize()
+                wall = time.time() - w0
+                if best is None or wall < best[0]:
+                    best = (wall, int(out.shape[1]) - args.cpu_prompt_len, d["target_call_times"])
+            cb["gpu_same_workload"] = {"value": best[1] / best[0], "unit": "tokens/s", "wall_s": best[0], "new_tokens": best[1],
+                                       "iterations": best[2], "max_len": n_tok, "prompt_len": args.cpu_prompt_len,
+                                       "note": "same prompt / max_len / gamma / top_k / top_p as cpu_baseline, both prefills included; "
+                                               "device Philox RNG (the CPU run draws from torch's generator)"}
+            if cb.get("value"):
+                cb["gpu_over_cpu_same_workload"] = cb["gpu_same_workload"]["value"] / cb["value"]
+            result["cpu_baseline"] = cb
         except Exception as e:          # never lose the GPU numbers to a host-side failure
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -58,6 +58,12 @@ int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temper
  * single CU can pull (~25 GB/s); without it one workgroup does everything.  Results are identical either way. */
 size_t sd_norm_workspace_bytes(int rows);
 
+/* top_k_top_p_filter by itself (utils.py:152-179; the reference mutates its argument and returns it): out[i] = logit
+ * where the token is kept, -inf where it is dropped; top_k == 0 and top_p == 0 leave the row untouched.  `out` must
+ * not alias `logits` (the Python drop-in copies the result back into its argument). */
+int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p, float *out,
+                        long ld_out, void *stream);
+
 /* One draft / autoregressive step's tail fused: norm_logits of ONE row followed by sample() on it
  * (kvcache_model.py:235-236 + :283), a single launch.  Writes the probability row (the accept scan and
  * the residual need it later) and the sampled token.  exp_noise / Philox as in sd_sample; with device
@@ -87,6 +93,14 @@ int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temp
  * distribution (negative / NaN / Inf), 2 = all-zero row; both are 'prob error' in the reference. */
 int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,
               uint64_t draw_index, int *tok_out, int *err_flag, void *stream);
+
+/* The device RNG of the throughput mode made observable, so that a test can replay the exact variates into the CPU
+ * oracle (the reference draws from torch's generator, utils.py:221 / speculative_sampling.py:1978; this build's
+ * device mode draws from counter-based Philox4x32-10 instead).  out[i] = the Exp(1) variate the sampling kernels use
+ * for vocabulary element i of draw (seed, draw_index): -log(u), u = (23 random bits + 1/2) * 2^-23 in (0,1). */
+int sd_philox_exp(uint64_t philox_seed, uint64_t draw_index, int V, float *out, void *stream);
+/* out[i] = the uniform in [0,1) the accept scans use for draw (seed, draw_index + i), i < n. */
+int sd_philox_uniform(uint64_t philox_seed, uint64_t draw_index, int n, float *out, void *stream);
 
 /* max_fn (utils.py:236-245) materialised: out = max(p-q,0) / (sum(max(p-q,0)) + 1e-6).  q may be
  * NULL (then max_fn(p)).  Only the drop-in sampling.utils.max_fn uses this; the decode loop uses

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("sd_version", _I, []),
     ("sd_last_error", C.c_char_p, []),
     ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP, _VP]),
+    ("sd_topk_topp_filter", _I, [_VP, _I, _I, _L, _I, _F, _VP, _L, _VP]),
     ("sd_norm_workspace_bytes", C.c_size_t, [_I]),
     ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_norm_batch", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, C.POINTER(SdNormRow), _I, _VP, _VP]),
@@ -82,6 +83,8 @@ SYMBOLS = [
     ("sd_accept_multi", _I, [C.POINTER(SdMultiItem), _I, _L, _I, _I, _VP, _U64, _U64, _VP, _VP]),
     ("sd_multi_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _VP, _U64, _U64, _VP, _VP]),
     ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_philox_exp", _I, [_U64, _U64, _I, _VP, _VP]),
+    ("sd_philox_uniform", _I, [_U64, _U64, _I, _VP, _VP]),
     ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),
     ("sd_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP, _VP]),

@@ -525,19 +525,19 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         ProfScope ps(s, PC_EMBED, st);
         hipLaunchKernelGGL((embed_norm_kernel<T>), dim3(n_new), dim3(256), norm_lds, st, tab, (const T *)m->w.embed, H,
                            llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, (const T *)m->n1w[0],
-                           (const T *)m->n1b[0], c.norm_eps, norm_kind, h);
+                           (const T *)m->n1b[0], c.norm_eps, norm_kind, h, c.vocab);
         SD_LAUNCH_CHECK();
     } else {
         if (llama || ED == H) {
             ProfScope ps(s, PC_EMBED, st);
             hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, H,
-                               llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, 0);
+                               llama ? (const T *)nullptr : (const T *)m->w.pos_embed, pos_off, x, 0, c.vocab);
             SD_LAUNCH_CHECK();
         } else {
             {
                 ProfScope ps(s, PC_EMBED, st);
                 hipLaunchKernelGGL((embed_kernel<T>), dim3(n_new), dim3(256), 0, st, tab, (const T *)m->w.embed, ED,
-                                   (const T *)nullptr, 0, eb, 1);
+                                   (const T *)nullptr, 0, eb, 1, c.vocab);
                 SD_LAUNCH_CHECK();
             }
             if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;

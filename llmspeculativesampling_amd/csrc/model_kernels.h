@@ -416,10 +416,12 @@ __device__ __forceinline__ f32x4 reduce_part4(const float *__restrict__ part, in
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, const T *__restrict__ pos_table,
-                             int pos_off, T *__restrict__ out, int tiled) {
+                             int pos_off, T *__restrict__ out, int tiled, int vocab) {
     const int row = blockIdx.x;
     const int pos = tab_pos(tab, row);
-    const int tok = tab.tok_base[tab_stream(tab, row)][pos];
+    // ids are validated on the host (IndexError, as nn.Embedding raises); the clamp only keeps a caller that goes
+    // straight to the C ABI with a bad id from reading outside the table
+    const int tok = min(max(tab.tok_base[tab_stream(tab, row)][pos], 0), vocab - 1);
     const T *src = table + (size_t)tok * dim;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * dim : nullptr;
     for (int i = threadIdx.x; i < dim; i += blockDim.x) {
@@ -507,13 +509,13 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(RowTab tab, const T *__
                                                         const T *__restrict__ pos_table, int pos_off,
                                                         T *__restrict__ x, const T *__restrict__ w,
                                                         const T *__restrict__ b, float eps, int kind,
-                                                        T *__restrict__ h) {
+                                                        T *__restrict__ h, int vocab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     float *red = xs + H;
     const int row = blockIdx.x;
     const int pos = tab_pos(tab, row);
-    const int tok = tab.tok_base[tab_stream(tab, row)][pos];
+    const int tok = min(max(tab.tok_base[tab_stream(tab, row)][pos], 0), vocab - 1);   // see embed_kernel
     const T *src = table + (size_t)tok * H;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * H : nullptr;
     for (int i = threadIdx.x; i < H; i += blockDim.x) {

@@ -98,7 +98,9 @@ __device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
     }
     return c;
 }
-__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+// 23 random bits + 1/2: (k + 0.5) * 2^-23 is exact in fp32 for every k < 2^23 and lies strictly inside (0,1), so
+// -log(u) is finite and > 0 (with 24 bits the top value rounds up to 1.0 and the exponential variate becomes 0)
+__device__ __forceinline__ float u01_open(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }     // (0,1)
 __device__ __forceinline__ float u01_half(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }           // [0,1)
 __device__ __forceinline__ float philox_exp(uint64_t seed, uint64_t draw, int elem) {
     const uint4 o = philox4x32(make_uint4((uint32_t)(elem >> 2), (uint32_t)draw, (uint32_t)(draw >> 32), 0x5D5Du),
@@ -271,7 +273,9 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                                                        int *__restrict__ err, const float *__restrict__ noise,
                                                        uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
                                                        int *__restrict__ samp_err, const CandRow *__restrict__ ws,
-                                                       NormTab tab, int use_tab) {
+                                                       NormTab tab, int use_tab, int filter_only) {
+    // filter_only: write top_k_top_p_filter's result (utils.py:152-179) - the scaled logit where kept, -inf where
+    // dropped - instead of the probabilities (the kept set itself, not "probability > 0", which underflow would shrink)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NormShared &S = *reinterpret_cast<NormShared *>(smem);
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     m = block_max(mt, S.redf);
     bad = block_sum_i(bad, S.redi);
     }
-    if (bad || m == INFINITY || m == -INFINITY) {                 // exp(log_softmax) would hold NaN (utils.py:203)
+    if (!filter_only && (bad || m == INFINITY || m == -INFINITY)) { // exp(log_softmax) would hold NaN (utils.py:203)
         for (int i = tid; i < V; i += NT) o[i] = __uint_as_float(0x7fc00000u);
         if (tid == 0) {
             if (errp) *errp = 1;
@@ -616,16 +620,17 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             for (int i = 0; i < kept; ++i) sum += expf(funkey(S.skey[i]) - m);
             S.lse = logf(sum);
         }
+        const float fillv = filter_only ? -INFINITY : 0.f;
         if (fast) {
             // norm_cand_kernel zero-filled the row
         } else if ((V & 3) == 0 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-            for (int i4 = tid; i4 < (V >> 2); i4 += NT) reinterpret_cast<float4 *>(o)[i4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i4 = tid; i4 < (V >> 2); i4 += NT) reinterpret_cast<float4 *>(o)[i4] = make_float4(fillv, fillv, fillv, fillv);
         } else {
-            for (int i = tid; i < V; i += NT) o[i] = 0.0f;
+            for (int i = tid; i < V; i += NT) o[i] = fillv;
         }
         __syncthreads();
         const float lse = S.lse;
-        if (tid < kept) o[S.sidx[tid]] = expf((funkey(S.skey[tid]) - m) - lse);
+        if (tid < kept) o[S.sidx[tid]] = filter_only ? funkey(S.skey[tid]) : expf((funkey(S.skey[tid]) - m) - lse);
         STAMP(5);
         if (SAMPLE) {
             // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and never
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             const float z = Z(i);
             const uint32_t kk = fkey(z);
             const bool keep = kk > cut_key || (kk == cut_key && i <= cut_idx);
+            if (filter_only) return keep ? z : -INFINITY;
             return keep ? expf((z - m) - lse) : 0.0f;
         };
         for (int i = tid; i < V; i += NT) o[i] = P(i);
@@ -940,13 +946,38 @@ __global__ __launch_bounds__(NT) void resample_batch_kernel(AcceptTab t, long ld
                   (int32_t *)nullptr, t.err_flags[b], t.n_err[b]);
 }
 
+// The device RNG made observable (tests replay it into the CPU oracle): out[i] = the Exp(1) variate element i of
+// draw (seed, draw) / the uniform of draw (seed, draw + i), exactly what the sampling kernels consume.
+__global__ void philox_exp_kernel(uint64_t seed, uint64_t draw, int V, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < V) out[i] = philox_exp(seed, draw, i);
+}
+__global__ void philox_uniform_kernel(uint64_t seed, uint64_t draw, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = philox_uniform(seed, draw + (uint64_t)i);
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+extern "C" int sd_philox_exp(uint64_t seed, uint64_t draw_index, int V, float *out, void *stream) {
+    SD_REQUIRE(out && V > 0, "sd_philox_exp: bad arguments");
+    hipLaunchKernelGGL(philox_exp_kernel, dim3((V + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, draw_index, V, out);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+extern "C" int sd_philox_uniform(uint64_t seed, uint64_t draw_index, int n, float *out, void *stream) {
+    SD_REQUIRE(out && n > 0, "sd_philox_uniform: bad arguments");
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed, draw_index, n, out);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
 static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
                        const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
-                       void *stream, const NormTab *tabp = nullptr) {
+                       void *stream, const NormTab *tabp = nullptr, int filter_only = 0) {
     NormTab tab = {};
     const int use_tab = tabp != nullptr;
     if (tabp) tab = *tabp;
@@ -974,14 +1005,23 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
     if (do_sample)
         hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
-                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab);
+                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0);
     else
         hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
                            (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
-                           (const CandRow *)ws, tab, use_tab);
+                           (const CandRow *)ws, tab, use_tab, filter_only);
     SD_LAUNCH_CHECK();
     return SD_OK;
+}
+
+// top_k_top_p_filter on its own (utils.py:152-179): out = logit where kept, -inf where dropped (out != logits).
+extern "C" int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p,
+                                   float *out, long ld_out, void *stream) {
+    SD_REQUIRE(logits && out && rows >= 0 && V > 0, "sd_topk_topp_filter: bad arguments");
+    if (rows == 0) return SD_OK;
+    return launch_norm(logits, rows, V, ld_in, 1.0f, top_k, top_p, 0, out, ld_out, nullptr, false, nullptr, 0, 0, nullptr,
+                       nullptr, nullptr, stream, nullptr, 1);
 }
 
 extern "C" size_t sd_norm_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandRow); }

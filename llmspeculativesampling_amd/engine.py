@@ -32,6 +32,30 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def check_token_ids(ids, vocab: int) -> None:
+    """nn.Embedding raises IndexError on an id outside [0, vocab) (reference modeling_llama.py:672, modeling_opt.py:
+    669); the HIP embedding gather has no such check, so every Python entry validates the ids it is handed
+    (a tokenizer's added pad / special token beyond the table is the usual way to get one)."""
+    if isinstance(ids, torch.Tensor):
+        if ids.numel() == 0:
+            return
+        lo, hi = int(ids.min()), int(ids.max())
+    else:
+        if not ids:
+            return
+        lo, hi = min(ids), max(ids)
+    if lo < 0 or hi >= vocab:
+        raise IndexError(f"index out of range in self: token id {lo if lo < 0 else hi} outside [0, {vocab})")
+
+
+def same_device(draft: "SpecDecModel", target: "SpecDecModel") -> None:
+    """The reference tolerates a draft and a target on different devices (x.to(device), speculative_sampling.py:
+    1949); here both models' kernels run on one stream, so raw pointers must belong to one GPU."""
+    if draft.device != target.device and (draft.device.index or 0) != (target.device.index or 0):
+        raise NotImplementedError(f"draft on {draft.device} and target on {target.device}: cross-device speculative "
+                                  "decoding is out of scope (place both models on one GPU)")
+
+
 class SpecDecModel:
     """Weights in HBM + sd_model handle.  Exposes what the reference reads off a model object:
     ``.config.is_encoder_decoder`` (speculative_sampling.py:1942) and ``.device`` (:1909)."""
@@ -188,14 +212,15 @@ class SpecDecModel:
 
     @classmethod
     def synthetic(cls, cfg: ModelConfig, seed: int, dtype=torch.bfloat16, device="cuda", max_pos=None,
-                  method: str = "torch", gain: float = 1.0, head_gain: float = 4.0) -> "SpecDecModel":
-        """Random-init weights generated tensor by tensor (never the whole model at once on the host)."""
+                  method: str = "torch", gain: float = 1.0, head_gain: float = 4.0, transform=None) -> "SpecDecModel":
+        """Random-init weights generated tensor by tensor (never the whole model at once on the host).
+        ``transform(name, tensor) -> tensor`` post-processes each generated tensor (synth.acceptance_dial_pair)."""
         from .synth import param_shapes, _scale
         import numpy as np
         shapes = {n: (i, s, k) for i, (n, s, k) in enumerate(param_shapes(cfg))}
         gen = torch.Generator(device=device)
 
-        def get(name: str) -> torch.Tensor:
+        def raw(name: str) -> torch.Tensor:
             idx, shape, kind = shapes[name]
             mean, std = _scale(kind, shape, gain, head_gain)
             if method == "numpy":
@@ -205,6 +230,10 @@ class SpecDecModel:
             gen.manual_seed(int(seed) * 100003 + idx)
             t = torch.empty(shape, dtype=torch.float32 if dtype == torch.float32 else torch.bfloat16, device=device)
             return t.normal_(mean, std, generator=gen)
+
+        def get(name: str) -> torch.Tensor:
+            t = raw(name)
+            return transform(name, t) if transform is not None else t
         m = cls(cfg, get, dtype=dtype, device=device, max_pos=max_pos)
         m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
         return m

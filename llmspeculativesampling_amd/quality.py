@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from .engine import as_specdec_model
+from .engine import as_specdec_model, check_token_ids
 
 
 @torch.no_grad()
@@ -15,6 +15,7 @@ def get_score(output: torch.Tensor, target_model, input_len: int) -> torch.Tenso
         raise NotImplementedError("encoder-decoder scoring (reference evaluation.py:126-132) is out of scope")
     assert output.dim() == 2 and output.size(0) == 1
     S = output.size(1)
+    check_token_ids(output, m.cfg.vocab_size)
     ses = m.new_session(S + 1)
     ids = output[0].to(device=m.device, dtype=torch.int32)
     logits = torch.empty((S, m.cfg.vocab_size), dtype=torch.float32, device=m.device)

@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 
 from .._lib import lib, check
-from ..engine import as_specdec_model, _stream
+from ..engine import as_specdec_model, _stream, check_token_ids
 from ..noise import DeviceNoise, HostTorchNoise
 from .kvcache_model import KVCacheModel
 
@@ -19,6 +19,7 @@ def autoregressive_sampling(x: torch.Tensor, model, N: int, eos_token_id: int, t
     dev = m.device
     V = m.cfg.vocab_size
     L0 = x.shape[1]
+    check_token_ids(x, V)
     if rng is None or rng == "host":
         noise = HostTorchNoise(dev)
     elif rng == "device":

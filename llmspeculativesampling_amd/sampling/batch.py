@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .._lib import lib, check, SdAcceptItem, SdAcceptResult, SdNormRow
-from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD
+from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device
 from ..noise import DeviceNoise
 from .kvcache_model import KVCacheModel
 
@@ -35,9 +35,12 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
     """B streams at once; ``prefixes[i]`` is (1, L_i) int64.  Returns a list of (1, len_i) tensors (and a list of
     ``details`` dicts with the reference's keys when ``details``).  Device Philox RNG, stream i seeded ``seeds[i]``."""
     draft_m, target_m = as_specdec_model(approx_model), as_specdec_model(target_model)
+    same_device(draft_m, target_m)
     dev = target_m.device
     V = target_m.cfg.vocab_size
     assert draft_m.cfg.vocab_size == V
+    for pf in prefixes:
+        check_token_ids(pf, V)
     B = len(prefixes)
     assert 1 <= B <= 16 and 1 <= gamma <= 16
     seeds = list(seeds) if seeds is not None else [int(torch.initial_seed()) + i for i in range(B)]

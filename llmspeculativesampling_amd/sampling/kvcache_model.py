@@ -13,8 +13,8 @@ from typing import Optional
 
 import torch
 
-from .._lib import lib, check
-from ..engine import SpecDecModel, Session, as_specdec_model, _stream, MAX_ROWS_PER_FORWARD
+from .._lib import lib, check, SdNormRow
+from ..engine import batch_forward, SpecDecModel, Session, as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, check_token_ids
 from ..noise import HostTorchNoise
 
 
@@ -37,6 +37,10 @@ class KVCacheModel:
         self._hist_len = 0                              # rows of _probs that are in the history
         self._hist_lo = 0                               # first row that was actually normalised
         self.event_log = None                           # bench: list of (start_evt, end_evt, n_new, upto) per forward
+        # width-w replicas of generate(multi=w, strategy="iid") (kvcache_model.py:180-200, 273-276): replica 0 is this
+        # object's own arenas; _width is the batch size the reference's cache would have right now
+        self._replicas = []                             # [(Session, probs, err, tok32)] for replicas 1..
+        self._width = 1
 
     # -- lazily sized arenas ----------------------------------------------------------------
     def _ensure(self, need: int):
@@ -59,12 +63,20 @@ class KVCacheModel:
     def _past_key_values(self):
         if self._session is None or self._session.cache_len == 0:
             return None
+        if self._width > 1:                             # (width, H_kv, S, D) like the reference's repeated cache
+            S = self._session.cache_len
+            kvs = [self._session.kv] + [r[0].kv for r in self._replicas[: self._width - 1]]
+            return [(torch.stack([kv[l, 0, :, :S, :] for kv in kvs]), torch.stack([kv[l, 1, :, :S, :] for kv in kvs]))
+                    for l in range(self._session.kv.shape[0])]
         return self._session.past_key_values()
 
     @property
     def _prob_history(self):
         if self._probs is None:
             return None
+        if self._width > 1:
+            return torch.stack([self._probs[: self._hist_len]] +
+                               [r[1][: self._hist_len] for r in self._replicas[: self._width - 1]])
         return self._probs[: self._hist_len].unsqueeze(0)
 
     @property
@@ -156,6 +168,7 @@ class KVCacheModel:
         self._ensure(S + 1)
         ses = self._session
         cached = ses.cache_len
+        check_token_ids(input_ids[0, cached:S], self._model.cfg.vocab_size)
         self._tok32[cached:S] = input_ids[0, cached:S].to(device=self._tok32.device, dtype=torch.int32)
         n_new = S - cached
         rows = n_new if (self._full_history or cached > 0) else 1
@@ -166,9 +179,14 @@ class KVCacheModel:
     @torch.no_grad()
     def generate(self, input: torch.Tensor, gamma: int, decoder_input_ids=None, attention_mask=None,
                  copy_cache_index=None, multi: int = 1, strategy: str = "beam") -> torch.Tensor:
-        """kvcache_model.py:300-310 -> :255-298 (multi == 1)."""
-        if multi != 1:
-            raise NotImplementedError("multi-draft strategies (reference kvcache_model.py:273-290) are out of scope")
+        """kvcache_model.py:300-310 -> :255-298: multi == 1, or multi > 1 with strategy="iid" (:273-276: the prefix
+        is repeated multi times, every replica samples its own continuation; returns (multi, S + gamma))."""
+        if multi > 1 or input.size(0) > 1 or self._width > 1:
+            if strategy == "beam" and multi > 1:
+                raise NotImplementedError                         # reference :286-287
+            if multi > 1 and strategy != "iid":
+                raise RuntimeError("Strategy Not Implemented " + strategy)      # reference :290
+            return self._generate_iid(input, gamma, max(int(multi), 1))
         from .utils import sample
         noise = self._noise or HostTorchNoise(self._model.device)
         x = input
@@ -178,14 +196,125 @@ class KVCacheModel:
             x = torch.cat((x, nxt.to(x.device)), dim=1)
         return x
 
+    def _grow_width(self, W: int) -> None:
+        """The reference's ``val.repeat(width, 1, 1, 1)`` / ``_prob_history.repeat(width, 1, 1)`` (kvcache_model.py:
+        180-192, 239-242): replicas 1..W-1 get their own arenas holding a copy of replica 0's rows."""
+        ses0 = self._session
+        m = self._model
+        while len(self._replicas) < W - 1:
+            ses = m.new_session(ses0.max_seq)
+            self._replicas.append((ses, torch.zeros_like(self._probs), torch.zeros_like(self._err),
+                                   torch.zeros_like(self._tok32)))
+        n, h = ses0.cache_len, self._hist_len
+        for ses, probs, err, tok in self._replicas[self._width - 1: W - 1]:
+            ses.kv[:, :, :, :n].copy_(ses0.kv[:, :, :, :n])
+            ses.cache_len = n
+            probs[:h].copy_(self._probs[:h])
+            tok[: n + 1].copy_(self._tok32[: n + 1])
+        self._width = W
+
+    def _generate_iid(self, input: torch.Tensor, gamma: int, multi: int) -> torch.Tensor:
+        assert input.dim() == 2
+        x = input.repeat(multi, 1) if multi > 1 else input     # (:273-274)
+        W, S0 = x.size(0), x.size(1)
+        m = self._model
+        V = m.cfg.vocab_size
+        dev = m.device
+        self._ensure(S0 + gamma + 1)
+        ses0 = self._session
+        if ses0.cache_len == 0:
+            # no cache yet: the reference runs the (W, S0) batch through the model; every row of x is fed on its own
+            # replica below, so replica 0 only needs its arenas to exist
+            pass
+        assert W >= self._width, "the batch cannot shrink without rollback(choice=)"
+        if W > self._width:
+            self._grow_width(W)
+        noise = self._noise or HostTorchNoise(dev)
+        on_dev = getattr(noise, "on_device", False)
+        sess = [ses0] + [r[0] for r in self._replicas[: W - 1]]
+        probs = [self._probs] + [r[1] for r in self._replicas[: W - 1]]
+        errs = [self._err] + [r[2] for r in self._replicas[: W - 1]]
+        toks = [self._tok32] + [r[3] for r in self._replicas[: W - 1]]
+        serr = torch.zeros(W, dtype=torch.int32, device=dev)
+        cached = ses0.cache_len
+        for w in range(W):
+            assert sess[w].cache_len == cached
+            check_token_ids(x[w, cached:], V)
+            toks[w][cached:S0] = x[w, cached:].to(device=dev, dtype=torch.int32)
+        ld_bytes = self._probs.stride(0) * 4
+        st = _stream()
+        per_pass = MAX_ROWS_PER_FORWARD
+        for i in range(gamma):
+            upto = S0 + i
+            n_new = upto - sess[0].cache_len
+            # rows whose probabilities enter the history: all new ones once a cache exists or with full_history
+            n_out = n_new if (self._full_history or sess[0].cache_len > 0) else 1
+            assert n_new * 1 <= per_pass, "one replica's uncached rows exceed a stream-batched pass; prefill with multi=1 first"
+            if on_dev:
+                e_base, seed, draw0 = 0, noise.seed, noise.next_draws(W)
+            else:
+                e = noise.exponential_rows(W, V)                  # ONE (W, V) draw, like torch.multinomial on (W, V)
+                e_base, seed, draw0 = e.data_ptr(), 0, 0
+            grp = max(1, per_pass // n_new)
+            for a in range(0, W, grp):
+                ws = list(range(a, min(W, a + grp)))
+                logits = batch_forward([sess[w] for w in ws], [toks[w] for w in ws], [n_new] * len(ws), [n_out] * len(ws))
+                rows = (SdNormRow * (len(ws) * n_out))()
+                k = 0
+                for w in ws:
+                    for r in range(n_out):
+                        pos = upto - n_out + r
+                        last = r == n_out - 1
+                        rows[k].probs_out = probs[w].data_ptr() + pos * ld_bytes
+                        rows[k].err = errs[w].data_ptr() + 4 * pos
+                        rows[k].exp_noise = (e_base + w * V * 4) if (e_base and last) else None
+                        rows[k].philox_seed = seed
+                        rows[k].draw_index = draw0 + w
+                        rows[k].tok_out = toks[w].data_ptr() + 4 * upto if last else serr.data_ptr()
+                        rows[k].sample_err = serr.data_ptr() + 4 * w if last else None
+                        k += 1
+                if n_out == 1:
+                    check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(self._temperature),
+                                            int(self._top_k or 0), float(self._top_p or 0.0), 0, rows, 1,
+                                            self._norm_ws.data_ptr(), st), "sd_norm_batch")
+                else:
+                    # several history rows per replica: normalise all of them, then sample each replica's last row
+                    check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(self._temperature),
+                                            int(self._top_k or 0), float(self._top_p or 0.0), 0, rows, 0,
+                                            self._norm_ws.data_ptr(), st), "sd_norm_batch")
+                    for w in ws:
+                        check(lib.sd_sample(probs[w][upto - 1].data_ptr(), V, (e_base + w * V * 4) if e_base else None,
+                                            seed, draw0 + w, toks[w][upto:].data_ptr(), serr[w:].data_ptr(), st), "sd_sample")
+            if self._hist_len == 0:
+                self._hist_lo = upto - n_out
+            self._hist_len = upto
+            if bool(serr.any()):
+                raise RuntimeError("prob error")
+            for w in range(W):
+                if bool(errs[w][upto - n_out:upto].any()):
+                    raise RuntimeError("norm logits error")
+        out = torch.stack([toks[w][: S0 + gamma] for w in range(W)]).to(torch.int64)
+        return out.to(input.device)
+
     @torch.no_grad()
     def rollback(self, end_pos: int, choice=None):
-        """kvcache_model.py:359-436, choice=None branch: O(1), nothing is copied."""
-        if choice is not None:
-            raise NotImplementedError("rollback(choice=) serves the multi-draft variants (out of scope)")
+        """kvcache_model.py:359-436: choice=None trims every replica (O(1), nothing is copied); an integer choice keeps
+        only that replica (``k[choice:choice+1, :, :end_pos, :]``, :390-392, 433-434): its arenas become this object's."""
         assert self._session is not None and self._session.cache_len > 0
+        end_pos = int(end_pos)
+        if choice is not None:
+            c = int(choice)
+            if not 0 <= c < self._width:
+                raise IndexError(f"choice {c} outside the {self._width} cached replicas")
+            if c > 0:
+                ses, probs, err, tok = self._replicas[c - 1]
+                self._replicas[c - 1] = (self._session, self._probs, self._err, self._tok32)
+                self._session, self._probs, self._err, self._tok32 = ses, probs, err, tok
+            self._width = 1
         self._session.rollback(end_pos)
-        self._hist_len = min(self._hist_len, int(end_pos))
+        for ses, _, _, _ in self._replicas[: self._width - 1]:
+            ses.rollback(end_pos)
+        self._hist_len = min(self._hist_len, end_pos)
 
     # -- out-of-scope beam / tree methods keep their names (SURVEY.md section 2, #10) --------
     def forward_tree_attention(self, *a, **k):

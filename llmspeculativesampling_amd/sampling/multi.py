@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .._lib import lib, check, SdMultiItem, SdMultiResult, SdNormRow, SpecDecError
-from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD
+from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device
 from .kvcache_model import KVCacheModel
 from .speculative_sampling import _make_noise
 
@@ -46,6 +46,7 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
         raise RuntimeError("Strategy not implemented " + strategy)         # reference :1548
     assert prefix.shape[0] == 1, "input batch size must be 1"
     draft_m, target_m = as_specdec_model(approx_model), as_specdec_model(target_model)
+    same_device(draft_m, target_m)
     dev = target_m.device
     V = target_m.cfg.vocab_size
     assert draft_m.cfg.vocab_size == V, "draft and target must share a vocabulary"
@@ -106,6 +107,8 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
     approx_calls = target_calls = 0
     out = host
     try:
+        if len(host) < T:
+            check_token_ids(host, V)                                   # nn.Embedding's IndexError, swallowed below
         while len(host) < T:
             L = len(host)
             tt = process_time_ns()
@@ -240,8 +243,8 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
                 break
     except SpecDecError:                                               # an engine failure is never swallowed
         raise
-    except RuntimeError as e:                                          # 'norm logits error' / 'prob error': printed and
-        print(e)                                                       # swallowed like the reference (:1696-1697)
+    except (RuntimeError, IndexError) as e:                            # 'norm logits error' / 'prob error' / a bad token id:
+        print(e)                                                       # printed and swallowed like the reference (:1689-1690)
 
     result = torch.tensor([out], dtype=torch.int64, device=prefix.device)
     if verbose:

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .._lib import lib, check, SdAcceptResult
-from ..engine import as_specdec_model, _stream
+from ..engine import as_specdec_model, _stream, check_token_ids, same_device
 from ..noise import DeviceNoise, HostTorchNoise
 from .kvcache_model import KVCacheModel
 
@@ -43,6 +43,7 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
     draft_m, target_m = as_specdec_model(approx_model), as_specdec_model(target_model)
     if draft_m.cfg.is_encoder_decoder or target_m.cfg.is_encoder_decoder:
         raise NotImplementedError("encoder-decoder models are out of scope")
+    same_device(draft_m, target_m)
     dev = target_m.device
     V = target_m.cfg.vocab_size
     assert draft_m.cfg.vocab_size == V, "draft and target must share a vocabulary"
@@ -52,6 +53,12 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
     T = seq_len0 + max_len
     cap = T + gamma + 2
     host_seq = [int(t) for t in prefix[0].tolist()]
+    if seq_len0 < T:
+        try:                                          # nn.Embedding's IndexError surfaces inside the reference's
+            check_token_ids(host_seq, V)              # try block and leaves as RuntimeError('s') (:1933, :2044-2046)
+        except IndexError as e:
+            print(e)
+            raise RuntimeError("s") from e
     ori_eos_cnt = sum(1 for t in host_seq if t == eos_token_id)
     noise = _make_noise(rng, dev)
 
@@ -201,7 +208,8 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                              draft._probs.stride(0), draft._session.logits.data_ptr(), draft._session.logits.stride(0),
                              target._session.logits.data_ptr(), target._session.logits.stride(0), err_words.data_ptr(),
                              res_dev.data_ptr(), target._norm_ws.data_ptr(), C.byref(sp)), "sd_spec_create")
-    if timing_log is not None:
+    timed = timing_log is not None or details          # HIP-event brackets around the draft and the verify phase
+    if timed:
         check(lib.sd_spec_timing(sp, 1), "sd_spec_timing")
     r_const = None
     if random_seed:
@@ -241,10 +249,15 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                 if bool(err_words[gamma:2 * gamma].any()):
                     raise RuntimeError("prob error")
                 raise RuntimeError("norm logits error")
-            if timing_log is not None:
+            if timed:
+                # the reference's approx_time / target_time are host process_time deltas around generate() (:1937-1962);
+                # here the host only enqueues, so the device time of the two phases (HIP events) is what is reported
                 check(lib.sd_spec_last_times(sp, C.byref(dms), C.byref(tms)), "sd_spec_last_times")
-                timing_log["draft_ms"].append(dms.value)
-                timing_log["target"].append((tms.value, L + gamma - target_len, L + gamma))
+                approx_time += int(dms.value * 1e6)
+                target_time += int(tms.value * 1e6)
+                if timing_log is not None:
+                    timing_log["draft_ms"].append(dms.value)
+                    timing_log["target"].append((tms.value, L + gamma - target_len, L + gamma))
             calls += 1
             l, n, t = res.n_accepted, res.n, res.next_token
             for i in range(gamma):
@@ -267,7 +280,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
                             break
                 out_tokens = host_seq[:cut]
                 break
-            other_time += process_time_ns() - tick
+            other_time += process_time_ns() - tick       # host CPU time of the iteration (enqueue + wait + bookkeeping)
     except Exception as e:
         print(e)
         lib.sd_spec_destroy(sp)
@@ -280,6 +293,7 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
             "approx_time": approx_time, "target_time": target_time, "other_time": other_time,
             "acc_len": acc_len, "acc_rate": np.mean(acc_rate),
             "target_call_times": calls, "approx_call_times": calls,
-            "target_model_time": 0, "target_pre_cache_time": 0, "target_post_prob_time": 0,
+            # the verify phase is one fused launch chain (forward + norm_probs, no cache preparation): all of it is model time
+            "target_model_time": target_time, "target_pre_cache_time": 0, "target_post_prob_time": 0,
         }
     return out

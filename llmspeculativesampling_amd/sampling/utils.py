@@ -35,9 +35,17 @@ def norm_logits(logits: torch.Tensor, temperature: float, top_k: float, top_p: f
 
 
 def top_k_top_p_filter(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0) -> torch.Tensor:
-    """reference utils.py:152-179: the kept support comes from the fused kernel (temperature 1)."""
-    probs = norm_logits(logits, 1.0, top_k, top_p)
-    return torch.where(probs > 0, logits, torch.full_like(logits, float("-inf")))
+    """reference utils.py:152-179: dropped tokens become -inf IN the argument, which is returned (utils.py:167, 177);
+    top_k == 0 and top_p == 0 leave it untouched.  The kept set comes from the kernel's own top-k / top-p decision,
+    not from "probability > 0" (a kept logit whose probability underflows stays kept)."""
+    assert logits.dim() == 2
+    x = _rows_f32(logits)
+    rows, V = x.shape
+    out = torch.empty_like(x)
+    check(lib.sd_topk_topp_filter(x.data_ptr(), rows, V, x.stride(0), int(top_k or 0), float(top_p or 0.0),
+                                  out.data_ptr(), out.stride(0), _stream()), "sd_topk_topp_filter")
+    logits.masked_fill_(out == float("-inf"), float("-inf"))
+    return logits
 
 
 def sample(probs: torch.Tensor, num_samples: int = 1, noise=None) -> torch.Tensor:

@@ -128,3 +128,52 @@ def perturb_state_dict(sd: Dict[str, torch.Tensor], seed: int, sigma: float) -> 
     if "model.decoder.embed_tokens.weight" in out:
         out["lm_head.weight"] = out["model.decoder.embed_tokens.weight"]
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Acceptance dial: a draft / target pair of the NAMED architectures whose next-token
+# distributions agree up to a knob, built without any checkpoint.  Every weight is still a dense random tensor that the
+# forward streams and multiplies (same bytes, same flops as a real checkpoint of that shape).
+#   * both models damp their residual branches (o_proj / down_proj scaled by eps), so the hidden state stays close to
+#     the token embedding and the distribution is close to lm_head . rmsnorm(embed[token]);
+#   * the target carries the base draft's embedding, final-norm weight and lm_head in its first `hd` hidden dims (the
+#     head scaled by sqrt(hd / H) to undo RMSNorm's 1/sqrt(H) over the wider row) and zeros in the others;
+#   * the knob sigma adds sigma * std * noise to the DRAFT's lm_head: sigma = 0 -> (almost) every draft accepted,
+#     growing sigma -> acceptance falls to ~0.  One target serves every sigma; drafts are 68 M parameters each.
+# ------------------------------------------------------------------------------------------------------------------
+_RESID = ("self_attn.o_proj.weight", "mlp.down_proj.weight")
+
+
+def dial_draft_transform(sigma: float, seed: int, resid_eps: float = 0.01):
+    """transform for SpecDecModel.synthetic / make_state_dict-style generators of the llama DRAFT."""
+    import torch as _t
+
+    def tf(name: str, t):
+        if name.endswith(_RESID):
+            return t * resid_eps
+        if name == "lm_head.weight" and sigma:
+            g = _t.Generator(device=t.device).manual_seed(int(seed) * 7919 + 17)
+            n = _t.empty(t.shape, dtype=_t.float32, device=t.device).normal_(0.0, 1.0, generator=g)
+            return (t.float() + float(sigma) * float(t.float().std()) * n).to(t.dtype)
+        return t
+    return tf
+
+
+def dial_target_transform(draft_get, draft_hidden: int, target_hidden: int, resid_eps: float = 0.002):
+    """transform for the llama TARGET: ``draft_get(name)`` regenerates the sigma = 0 draft's tensors."""
+    hd, H = int(draft_hidden), int(target_hidden)
+    scale = float(np.sqrt(hd / H))
+
+    def tf(name: str, t):
+        if name.endswith(_RESID):
+            return t * resid_eps
+        if name == "model.embed_tokens.weight":
+            t[:, hd:] = 0
+            t[:, :hd] = draft_get(name).to(device=t.device, dtype=t.dtype)
+        elif name == "model.norm.weight":
+            t[:hd] = draft_get(name).to(device=t.device, dtype=t.dtype)
+        elif name == "lm_head.weight":
+            t[:, hd:] = 0
+            t[:, :hd] = (draft_get(name).to(device=t.device).float() * scale).to(t.dtype)
+        return t
+    return tf

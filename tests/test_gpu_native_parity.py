@@ -1,0 +1,420 @@
+"""Round-2 parity tests (`pytest -m gpu`): the paths bench.py actually times - the native device-RNG iteration
+(sd_spec_iteration), the stream-batched loop and the bf16 fused kernels at the headline shapes - held to the CPU oracle,
+plus the drop-in boundary (HF modules, KVCacheModel multi / choice, bad token ids, top_k_top_p_filter).
+
+The device RNG is replayed into the oracle through sd_philox_exp / sd_philox_uniform (tests/philox_replay.py), so the
+comparison is token for token, not statistical.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from golden_io import logits_row
+from philox_replay import PhiloxOracleNoise
+from llmspeculativesampling_amd.config import ModelConfig, load_config
+from llmspeculativesampling_amd.synth import make_state_dict, perturb_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import types
+    import llmspeculativesampling_amd.sampling as S
+    from llmspeculativesampling_amd import _lib, engine, noise
+    return types.SimpleNamespace(S=S, lib=_lib.lib, L=_lib, engine=engine, noise=noise)
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pair(kind, seed=11):
+    """(cfg_d, sd_d, cfg_t, sd_t) fp32 tiny pairs: correlated / identical / unrelated Llama, OPT pre-LN -> post-LN."""
+    if kind == "opt":
+        dc, tc = load_config("tiny-opt-pre"), load_config("tiny-opt-post")
+        return dc, make_state_dict(dc, seed), tc, make_state_dict(tc, seed + 1)
+    cfg = load_config("tiny-llama-target")
+    dsd = make_state_dict(cfg, seed)
+    if kind == "same":
+        return cfg, dsd, cfg, dsd
+    if kind == "unrelated":
+        return cfg, dsd, cfg, make_state_dict(cfg, seed + 5)
+    return cfg, dsd, cfg, perturb_state_dict(dsd, seed + 1, 0.12)
+
+
+# --------------------------------------------------------------------------- Philox stream itself
+def test_philox_variates_are_strictly_positive_and_in_range(hip):
+    """u = (23 bits + 1/2) * 2^-23 lies strictly inside (0,1), so Exp(1) = -log(u) is finite and > 0 for
+    every counter; the uniforms of the accept scan lie in [0,1).  Swept over 64 draws x 32000 elements."""
+    V = 32000
+    e = torch.empty(V, dtype=torch.float32, device="cuda")
+    lo, hi = float("inf"), 0.0
+    for d in range(64):
+        assert hip.lib.sd_philox_exp(987654321 + d, d * 7919, V, e.data_ptr(), _st()) == 0
+        lo, hi = min(lo, float(e.min())), max(hi, float(e.max()))
+    assert lo > 0.0 and np.isfinite(hi) and hi < 17.0            # -log(2^-24) = 16.6
+    u = torch.empty(4096, dtype=torch.float32, device="cuda")
+    assert hip.lib.sd_philox_uniform(5, 0, 4096, u.data_ptr(), _st()) == 0
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and 0.45 < float(u.mean()) < 0.55
+    m = float(torch.stack([e]).mean())
+    assert 0.95 < m < 1.05                                       # Exp(1) mean
+
+
+# --------------------------------------------------------------------------- native iteration vs the oracle
+NATIVE_CASES = [
+    ("corr_g4", "corr", dict(gamma=4, top_k=20, top_p=0.9), 2, 24),
+    ("corr_g2", "corr", dict(gamma=2, top_k=20, top_p=0.9), 2, 24),
+    ("corr_g8", "corr", dict(gamma=8, top_k=20, top_p=0.9), 2, 30),
+    ("corr_plain_softmax", "corr", dict(gamma=4, top_k=0, top_p=0.0), 2, 20),
+    ("same_all_accept", "same", dict(gamma=4, top_k=10, top_p=0.0), 2, 24),
+    ("unrelated", "unrelated", dict(gamma=4, top_k=20, top_p=0.9), 2, 16),
+    ("seeded_quirk", "corr", dict(gamma=4, top_k=20, top_p=0.9, random_seed=42), 2, 24),
+    ("opt_pre_to_post", "opt", dict(gamma=4, top_k=20, top_p=0.9), 2, 20),
+    ("eos_stop", "corr", dict(gamma=4, top_k=5, top_p=0.0), None, 40),     # eos chosen from the oracle's own output
+]
+
+
+@pytest.mark.parametrize("name,kind,kw,eos,max_len", NATIVE_CASES, ids=[c[0] for c in NATIVE_CASES])
+def test_native_device_loop_equals_oracle_on_the_device_rng_stream(hip, name, kind, kw, eos, max_len):
+    """speculative_sampling(rng=DeviceNoise(seed)) -> _native_device_loop -> sd_spec_iteration (what bench.py times)
+    against oracle.speculative_sampling fed the SAME Philox variates: ids, acc_len, call counts identical (fp32)."""
+    dc, dsd, tc, tsd = _pair(kind)
+    prompt = torch.from_numpy(np.random.default_rng(5).integers(3, dc.vocab_size, size=(1, 13)))
+    seed = 4242
+    if eos is None:                                              # pick a token the run really generates
+        nz = PhiloxOracleNoise(hip.lib, seed, kw["gamma"], _st)
+        full = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dc, dsd), oracle.RefCausalLM(tc, tsd), -1, None,
+                                           max_len, noise=nz, **kw)
+        eos = int(full[0, 13 + 9])
+    nz = PhiloxOracleNoise(hip.lib, seed, kw["gamma"], _st)
+    want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dc, dsd), oracle.RefCausalLM(tc, tsd), eos, None,
+                                           max_len, details=True, noise=nz, **kw)
+    dm = hip.engine.SpecDecModel.from_state_dict(dc, dsd, dtype=torch.float32)
+    tm = dm if kind == "same" else hip.engine.SpecDecModel.from_state_dict(tc, tsd, dtype=torch.float32)
+    got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, eos, None, max_len, details=True,
+                                         rng=hip.noise.DeviceNoise(seed), **kw)
+    np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+    assert gd["acc_len"] == wd["acc_len"]
+    assert gd["target_call_times"] == wd["target_call_times"] and gd["approx_call_times"] == wd["approx_call_times"]
+    assert abs(float(gd["acc_rate"]) - float(wd["acc_rate"])) < 1e-4
+    if name == "eos_stop":
+        assert got.shape[1] < 13 + max_len and int(got[0, -1]) == eos
+    if name == "same_all_accept":
+        assert all(a == kw["gamma"] for a in gd["acc_len"])
+    # native mode reports the device time of the two phases (HIP events) where the reference reports process_time
+    assert gd["approx_time"] > 0 and gd["target_time"] > 0 and gd["target_model_time"] == gd["target_time"]
+
+
+def test_stream_batched_loop_equals_oracle_per_stream(hip):
+    """speculative_sampling_batch (throughput mode: B streams through shared weight passes) against B separate oracle
+    runs, each fed its own stream's Philox variates; one stream stops at EOS while the others continue."""
+    dc, dsd, tc, tsd = _pair("corr", seed=21)
+    V = dc.vocab_size
+    prompts = [torch.from_numpy(np.random.default_rng(40 + i).integers(3, V, size=(1, 9 + 2 * i))) for i in range(4)]
+    seeds = [900 + i for i in range(4)]
+    kw = dict(gamma=4, top_k=20, top_p=0.9)
+    od, ot = oracle.RefCausalLM(dc, dsd), oracle.RefCausalLM(tc, tsd)
+    probe = oracle.speculative_sampling(prompts[1], od, ot, -1, None, 24, noise=PhiloxOracleNoise(hip.lib, seeds[1], 4, _st), **kw)
+    eos = int(probe[0, prompts[1].shape[1] + 6])
+    wants = []
+    for p, sd_ in zip(prompts, seeds):
+        wants.append(oracle.speculative_sampling(p, od, ot, eos, None, 24, details=True,
+                                                 noise=PhiloxOracleNoise(hip.lib, sd_, 4, _st), **kw))
+    dm = hip.engine.SpecDecModel.from_state_dict(dc, dsd, dtype=torch.float32)
+    tm = hip.engine.SpecDecModel.from_state_dict(tc, tsd, dtype=torch.float32)
+    outs, ds = hip.S.speculative_sampling_batch([p.cuda() for p in prompts], dm, tm, eos, None, 24, details=True,
+                                                seeds=seeds, **kw)
+    stopped = 0
+    for (want, wd), got, gd in zip(wants, outs, ds):
+        np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+        assert gd["acc_len"] == wd["acc_len"] and gd["target_call_times"] == wd["target_call_times"]
+        stopped += int(want[0, -1]) == eos
+    assert 1 <= stopped < 4
+
+
+def test_autoregressive_device_rng_equals_oracle(hip):
+    cfg = load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 31)
+    prompt = torch.from_numpy(np.random.default_rng(6).integers(3, cfg.vocab_size, size=(1, 11)))
+    want = oracle.autoregressive_sampling(prompt, oracle.RefCausalLM(cfg, sd), 20, -1, 1.0, 20, 0.9,
+                                          noise=PhiloxOracleNoise(hip.lib, 77, 1, _st))
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    got = hip.S.autoregressive_sampling(prompt.cuda(), m, 20, -1, 1.0, 20, 0.9, rng=hip.noise.DeviceNoise(77))
+    np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+
+
+# --------------------------------------------------------------------------- bf16 native path
+BF16_CFG = dict(arch="llama", vocab_size=8192, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6)
+
+
+@pytest.mark.parametrize("case", ["perturbed", "all_accept", "long_prompt", "split_lm_head"])
+def test_native_bf16_iteration_bit_equals_python_loop(hip, case, capsys):
+    """The benchmarked configuration (bf16 weights, sd_spec_iteration, device Philox, vocab wide enough for the
+    16-workgroup norm fast path, lm_head output slab handed straight to the norm) against the Python-orchestrated HIP
+    loop (verbose=True) under the same Philox seed: tokens, acc_len and acc_rate must be bit-equal.  Covers a pair with
+    partial accepts, an all-accept pair (rollback(n+2), 2-row draft step, bonus sample), a prompt longer than one
+    256-row prefill chunk, and the logits_kernel fallback (lm_head forced to split its k-range via SD_GEMM_UNITS)."""
+    cfg = ModelConfig(**BF16_CFG)
+    dsd = make_state_dict(cfg, 5, dtype=torch.bfloat16)
+    if case == "all_accept":
+        tsd = dsd
+    else:
+        tsd = {k: v.to(torch.bfloat16) for k, v in perturb_state_dict({a: b.float() for a, b in dsd.items()}, 6, 0.05).items()}
+    L = 300 if case == "long_prompt" else 24
+    prompt = torch.from_numpy(np.random.default_rng(3).integers(3, cfg.vocab_size, size=(1, L))).cuda()
+    dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.bfloat16)
+    tm = dm if case == "all_accept" else hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.bfloat16)
+    if case == "split_lm_head":
+        os.environ["SD_GEMM_UNITS"] = "1536"                     # 512 n-tiles -> 3 k-slabs: the head leaves partial slabs
+    try:
+        kw = dict(gamma=4, top_k=20, top_p=0.9)
+        a, da = hip.S.speculative_sampling(prompt, dm, tm, -1, None, 40, details=True, rng=hip.noise.DeviceNoise(123), **kw)
+        b, db = hip.S.speculative_sampling(prompt, dm, tm, -1, None, 40, details=True, rng=hip.noise.DeviceNoise(123),
+                                           verbose=True, **kw)
+    finally:
+        os.environ.pop("SD_GEMM_UNITS", None)
+    capsys.readouterr()
+    assert torch.equal(a, b)
+    assert da["acc_len"] == db["acc_len"] and da["target_call_times"] == db["target_call_times"]
+    assert float(da["acc_rate"]) == float(db["acc_rate"])
+    if case == "all_accept":
+        assert all(x == 4 for x in da["acc_len"])
+    if case == "perturbed":
+        assert 0 < sum(da["acc_len"]) < 4 * len(da["acc_len"])   # partial accepts really occur
+
+
+# --------------------------------------------------------------------------- headline shapes vs the oracle
+def _host_sd(m):
+    sd = {n: m._synth_get(n).cpu() for n in m._synth_names}
+    return sd
+
+
+def test_headline_shapes_bf16_error_against_fp32_truth(hip):
+    """A 2-layer model with Llama-2-13b's layer shape (hidden 5120, 40 heads x 128, inter 13824, vocab 32000), bf16:
+    the HIP forward's error against an fp32 forward of the same (bf16-valued) weights, next to the error of the
+    reference's own bf16 arithmetic (oracle in bf16, which rounds where the reference rounds).  Bar: HIP error <= 1.5x
+    the reference-bf16 error (+ a small absolute floor), on the prefill rows and on a gamma+1-row verify."""
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=256, rms_norm_eps=1e-5)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=64)
+    sd16 = _host_sd(m)
+    sd32 = {k: v.float() for k, v in sd16.items()}
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 29)))
+    o16, o32 = oracle.RefCausalLM(cfg, sd16), oracle.RefCausalLM(cfg, sd32)
+    ses = m.new_session(64)
+    past16 = past32 = None
+    pos = 0
+    for q in (24, 5):
+        chunk = ids[:, pos:pos + q]
+        r16 = o16(chunk, past_key_values=past16)
+        r32 = o32(chunk, past_key_values=past32)
+        past16, past32 = r16.past_key_values, r32.past_key_values
+        nl = min(q, 5)
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), nl).cpu()
+        truth = r32.logits[0, -nl:]
+        e_hip = float((got - truth).abs().max())
+        e_ref = float((r16.logits.float()[0, -nl:] - truth).abs().max())
+        rms_hip = float((got - truth).pow(2).mean().sqrt())
+        rms_ref = float((r16.logits.float()[0, -nl:] - truth).pow(2).mean().sqrt())
+        print(f"rows {q}: max err hip {e_hip:.4f} ref-bf16 {e_ref:.4f}; rms hip {rms_hip:.5f} ref-bf16 {rms_ref:.5f}; "
+              f"|logit| max {float(truth.abs().max()):.2f}")
+        assert rms_hip <= 1.5 * rms_ref + 1e-3, (q, rms_hip, rms_ref)
+        assert e_hip <= 1.5 * e_ref + 0.02, (q, e_hip, e_ref)
+        pos += q
+
+
+def test_headline_pair_first_verify_vs_oracle_full_size(hip):
+    """BASELINE configs[1] at its real shapes: llama-68m -> Llama-2-13b, bf16, the same synthetic weights on the GPU and
+    in the oracle (torch-CPU bf16).  A 24-token prompt, 4 drafted tokens: the HIP target's logits for the gamma+1 verify
+    rows and the p_hist rows norm_probs makes of them (T=1, k=20, p=0.9) against oracle.RefCausalLM + oracle.norm_logits;
+    the draft's prefill + one step likewise.  bf16 through 40 layers: logits within 4 % of the logit scale, total
+    variation of every probability row <= 0.10, and the top-1 token agrees wherever the oracle's margin is clear."""
+    dcfg, tcfg = load_config("llama-68m"), load_config("llama-2-13b")
+    dm = hip.engine.SpecDecModel.synthetic(dcfg, seed=1, dtype=torch.bfloat16, max_pos=64)
+    tm = hip.engine.SpecDecModel.synthetic(tcfg, seed=2, dtype=torch.bfloat16, max_pos=64)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ids = torch.from_numpy(np.random.default_rng(8).integers(3, tcfg.vocab_size, size=(1, 28)))
+    for m, cfg, name in ((tm, tcfg, "target"), (dm, dcfg, "draft")):
+        om = oracle.RefCausalLM(cfg, _host_sd(m))
+        ses = m.new_session(64)
+        r = om(ids[:, :23])
+        ses.forward(ids[0, :23].to(torch.int32).cuda(), 0)
+        r2 = om(ids[:, 23:28], past_key_values=r.past_key_values)
+        got = ses.forward(ids[0, 23:28].to(torch.int32).cuda(), 5)
+        want = r2.logits.float()[0]
+        scale = float(want.abs().max())
+        err = float((got.cpu() - want).abs().max())
+        print(f"{name}: verify-row logits max err {err:.4f} of scale {scale:.2f}")
+        assert err <= 0.04 * scale, (name, err, scale)
+        p_hip = hip.S.norm_logits(got, 1.0, 20, 0.9).cpu()
+        for i in range(5):
+            p_ref = oracle.norm_logits(want[i:i + 1], 1.0, 20, 0.9)[0]
+            tv = 0.5 * float((p_hip[i] - p_ref).abs().sum())
+            assert tv <= 0.10, (name, i, tv)
+            top2 = torch.topk(want[i], 2).values
+            if float(top2[0] - top2[1]) > 4 * err:
+                assert int(p_hip[i].argmax()) == int(p_ref.argmax())
+        del om
+
+
+def test_acceptance_dial_pair_accept_length_vs_oracle(hip):
+    """bench.py's acceptance dial (synth.py): on a reduced pair with the dial construction (draft hidden 256 inside a
+    target of hidden 512, 3 layers) the mean accept length falls monotonically with sigma, sigma = 0 is (nearly)
+    all-accept, and the oracle replaying the device's Philox stream on the same weights gives the same accept
+    lengths statistically (bf16 rounding may flip individual tokens)."""
+    from llmspeculativesampling_amd.synth import dial_draft_transform, dial_target_transform
+    dcfg = ModelConfig(arch="llama", vocab_size=4096, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                       num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256, rms_norm_eps=1e-5)
+    tcfg = ModelConfig(arch="llama", vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                       num_attention_heads=4, num_key_value_heads=4, max_position_embeddings=256, rms_norm_eps=1e-5)
+    base = hip.engine.SpecDecModel.synthetic(dcfg, seed=11, dtype=torch.bfloat16, transform=dial_draft_transform(0.0, 11))
+    tgt = hip.engine.SpecDecModel.synthetic(tcfg, seed=12, dtype=torch.bfloat16,
+                                            transform=dial_target_transform(base._synth_get, 256, 512))
+    prompt = torch.from_numpy(np.random.default_rng(2).integers(3, 4096, size=(1, 20)))
+    means = []
+    for sg in (0.0, 0.1, 0.3, 1.0):
+        drf = base if sg == 0.0 else hip.engine.SpecDecModel.synthetic(dcfg, seed=11, dtype=torch.bfloat16,
+                                                                       transform=dial_draft_transform(sg, 11))
+        out, d = hip.S.speculative_sampling(prompt.cuda(), drf, tgt, -1, None, 60, gamma=4, top_k=20, top_p=0.9, details=True,
+                                            rng=hip.noise.DeviceNoise(55))
+        means.append(float(np.mean(d["acc_len"])))
+        if sg == 0.1:
+            want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dcfg, _host_sd(drf)),
+                                                   oracle.RefCausalLM(tcfg, _host_sd(tgt)), -1, None, 60, gamma=4, top_k=20,
+                                                   top_p=0.9, details=True, noise=PhiloxOracleNoise(hip.lib, 55, 4, _st))
+            assert abs(float(np.mean(wd["acc_len"])) - means[-1]) <= 0.6, (wd["acc_len"], d["acc_len"])
+    print("mean accept length per sigma:", means)
+    assert means[0] >= 3.5 and means[-1] <= 1.0
+    assert all(means[i] >= means[i + 1] - 0.3 for i in range(len(means) - 1))
+
+
+# --------------------------------------------------------------------------- drop-in boundary
+def _hf_pair():
+    import transformers
+    lc = transformers.LlamaConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, intermediate_size=128,
+                                  num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128,
+                                  rms_norm_eps=1e-5, tie_word_embeddings=False)
+    oc = transformers.OPTConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, ffn_dim=128, num_attention_heads=4,
+                                max_position_embeddings=128, do_layer_norm_before=True, word_embed_proj_dim=64)
+    torch.manual_seed(3)
+    return transformers.LlamaForCausalLM(lc).eval(), transformers.OPTForCausalLM(oc).eval()
+
+
+@pytest.mark.parametrize("arch", ["llama", "opt"])
+def test_hf_module_as_model_matches_state_dict_path_and_the_module_itself(hip, arch):
+    """INTEGRATION.md's route: a transformers LlamaForCausalLM / OPTForCausalLM (random-init, as evaluation.py:183-253
+    would hand over a loaded one) passed straight to speculative_sampling.  as_specdec_model / from_hf must give the ids
+    of the from_state_dict path, the conversion must be cached per module, and the engine's logits must match the
+    module's own forward (stock transformers, fp32, 1e-3)."""
+    from llmspeculativesampling_amd.config import config_from_hf
+    llama, opt = _hf_pair()
+    mod = llama if arch == "llama" else opt
+    cfg = config_from_hf(mod.config)
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    if arch == "opt":
+        sd.setdefault("lm_head.weight", sd["model.decoder.embed_tokens.weight"])
+    prompt = torch.from_numpy(np.random.default_rng(1).integers(3, 512, size=(1, 12)))
+    torch.manual_seed(5)
+    a = hip.S.speculative_sampling(prompt.cuda(), mod, mod, 2, None, 12, gamma=3, top_k=10, top_p=0.9)
+    m2 = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    torch.manual_seed(5)
+    b = hip.S.speculative_sampling(prompt.cuda(), m2, m2, 2, None, 12, gamma=3, top_k=10, top_p=0.9)
+    assert torch.equal(a, b)
+    assert hip.engine.as_specdec_model(mod) is hip.engine.as_specdec_model(mod)
+    with torch.no_grad():
+        want = mod(prompt).logits[0].float()
+    ses = hip.engine.as_specdec_model(mod).new_session(32)
+    got = ses.forward(prompt[0].to(torch.int32).cuda(), 12).cpu()
+    assert float((got - want).abs().max()) <= 1e-3
+    # the oracle on the module's weights agrees on the tokens under the same host seed (full drop-in chain)
+    torch.manual_seed(5)
+    om = oracle.RefCausalLM(cfg, sd)
+    c = oracle.speculative_sampling(prompt, om, om, 2, None, 12, gamma=3, top_k=10, top_p=0.9)
+    np.testing.assert_array_equal(a.cpu().numpy(), c.numpy())
+
+
+def test_kvcache_model_multi_iid_and_rollback_choice_match_oracle(hip):
+    """KVCacheModel.generate(x, gamma, multi=w, strategy="iid") and rollback(end, choice) on the drop-in class
+    (reference kvcache_model.py:273-276, 180-200, 239-244, 390-396, 433-436): tokens of every replica, the (w, S, V)
+    probability history and the (w, H, S, D) cache shape against the oracle wrapper fed the same noise."""
+    cfg = load_config("tiny-llama-target")
+    sd = make_state_dict(cfg, 12)
+    V = cfg.vocab_size
+    prompt = torch.from_numpy(np.random.default_rng(7).integers(3, V, size=(1, 9)))
+    rec = oracle.RecordingNoise()
+    torch.manual_seed(1)
+    ok = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1.0, 20, 0.9, rec)
+    x1 = ok.generate(prompt, 2)                                   # batch 1: prefill + 2 tokens
+    x3 = ok.generate(x1, 3, multi=3, strategy="iid")              # 3 replicas, 3 tokens each
+    hist3 = ok._prob_history.clone()
+    ok.rollback(x3.shape[1] - 2, choice=1)
+    x4 = ok.generate(x3[1:2, :x3.shape[1] - 1], 2)                # continue replica 1 alone
+
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    kv = hip.S.KVCacheModel(m, 1.0, 20, 0.9, noise=hip.noise.ReplayNoise(rec.events, "cuda"))
+    y1 = kv.generate(prompt.cuda(), 2)
+    np.testing.assert_array_equal(y1.cpu().numpy(), x1.numpy())
+    y3 = kv.generate(y1, 3, multi=3, strategy="iid")
+    np.testing.assert_array_equal(y3.cpu().numpy(), x3.numpy())
+    ph = kv._prob_history
+    assert tuple(ph.shape) == tuple(hist3.shape)
+    np.testing.assert_allclose(ph.cpu().numpy(), hist3.numpy(), atol=1e-5)
+    k0, v0 = kv._past_key_values[0]
+    assert tuple(k0.shape) == (3, cfg.num_key_value_heads, x3.shape[1] - 1, cfg.head_dim)
+    kv.rollback(x3.shape[1] - 2, choice=1)
+    assert tuple(kv._prob_history.shape) == (1, x3.shape[1] - 2, V)
+    assert tuple(kv._past_key_values[0][0].shape) == (1, cfg.num_key_value_heads, x3.shape[1] - 2, cfg.head_dim)
+    y4 = kv.generate(y3[1:2, :y3.shape[1] - 1], 2)
+    np.testing.assert_array_equal(y4.cpu().numpy(), x4.numpy())
+    with pytest.raises(NotImplementedError):
+        kv.generate(y4, 1, multi=2, strategy="beam")
+
+
+def test_out_of_range_token_ids_raise_like_the_reference(hip, capsys):
+    """nn.Embedding raises IndexError for an id outside the table (a tokenizer's added pad id is the usual case); the
+    reference's speculative_sampling wraps it into RuntimeError('s') (speculative_sampling.py:2044-2046), its
+    autoregressive_sampling lets it through.  The HIP gather itself must never read outside the table."""
+    cfg = load_config("tiny-llama-target")
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, make_state_dict(cfg, 12), dtype=torch.float32)
+    V = cfg.vocab_size
+    bad = torch.tensor([[5, 6, V, 7]], device="cuda")
+    neg = torch.tensor([[5, -1, 7]], device="cuda")
+    for x in (bad, neg):
+        with pytest.raises(RuntimeError, match="^s$"):
+            hip.S.speculative_sampling(x, m, m, 2, None, 4)
+        with pytest.raises(IndexError):
+            hip.S.autoregressive_sampling(x, m, 4, 2)
+        with pytest.raises(IndexError):
+            hip.S.KVCacheModel(m)._forward_with_kvcache(x)
+    capsys.readouterr()
+    assert torch.equal(hip.S.speculative_sampling(bad, m, m, 2, None, 0), bad)       # max_len 0 never touches the model
+    # straight through the C ABI: clamped, finite logits, no fault
+    ses = m.new_session(16)
+    out = ses.forward(torch.tensor([5, V + 1000, -7], dtype=torch.int32, device="cuda"), 3)
+    assert bool(torch.isfinite(out).all())
+
+
+def test_top_k_top_p_filter_in_place_and_support(hip):
+    """reference utils.py:152-179: the argument is mutated and returned; k = 0, p = 0 leaves it untouched; the kept set is
+    the filter's own decision (a kept logit whose probability underflows stays finite)."""
+    x = logits_row(77, 1000, 3.0).cuda()
+    keep = x.clone()
+    y = hip.S.top_k_top_p_filter(x, 0, 0.0)
+    assert y is x and torch.equal(x, keep)
+    want = oracle.top_k_top_p_filter(keep.cpu(), 20, 0.9)
+    y = hip.S.top_k_top_p_filter(x, 20, 0.9)
+    assert y is x
+    assert torch.equal(torch.isinf(x.cpu()), torch.isinf(want))
+    assert torch.equal(x.cpu()[~torch.isinf(want)], want[~torch.isinf(want)])
+    # underflow: second-largest logit is 200 below the top one -> probability 0 in fp32, still inside top-k = 3
+    z = torch.full((1, 64), -500.0, device="cuda")
+    z[0, 3], z[0, 9], z[0, 11] = 50.0, -150.0, -160.0
+    w = hip.S.top_k_top_p_filter(z.clone(), 3, 0.0)
+    assert sorted(torch.nonzero(torch.isfinite(w[0])).flatten().tolist()) == [3, 9, 11]
+    ow = oracle.top_k_top_p_filter(z.cpu(), 3, 0.0)
+    assert torch.equal(torch.isfinite(w.cpu()), torch.isfinite(ow))

@@ -199,3 +199,42 @@ def test_sampling_package_exports_every_reference_name():
               "random_width_beam_sampling", "beam_speculative_sampling_v2"):
         with pytest.raises(NotImplementedError):
             getattr(S, n)(None, None, None)
+
+
+# --------------------------------------------------------------------------- bench.py launcher
+def _run_bench(extra_args, extra_env, timeout=180):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPECDEC_BENCH_STUB="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` (the driver's command shape, no launcher environment) must itself start 2 ranks that
+    rendezvous on 127.0.0.1, run the timed protocol and print ONE JSON line with n_gpus = 2 (stub decode step, gloo)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--prompt-len", "8", "--max-len", "4"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["new_tokens"] == 2 * 3 * 4 and d["scaling"] == "weak"
+
+
+def test_bench_single_rank_and_world_mismatch():
+    import json
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "0", "--prompt-len", "8", "--max-len", "4"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+    # a launcher environment that disagrees with --gpus is an error, never a mislabelled line
+    r = _run_bench(["--gpus", "2", "--steps", "1"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_propagates_rank_failure():
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--prompt-len", "8", "--max-len", "4"], {"SPECDEC_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0
