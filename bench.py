@@ -57,7 +57,7 @@ def parse(argv=None):
     ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
     ap.add_argument("--accept-sweep", type=int, default=1,
                     help="after the headline, time the same workload on the acceptance-dial pair at each --sweep-sigmas (N=1)")
-    ap.add_argument("--sweep-sigmas", default="0,0.04,0.08,0.16,0.32")
+    ap.add_argument("--sweep-sigmas", default="0,0.04,0.08,0.16,0.32,1.0")
     ap.add_argument("--sweep-steps", type=int, default=2)
     return ap.parse_args(argv)
 

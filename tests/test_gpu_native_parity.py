@@ -289,7 +289,7 @@ def test_acceptance_dial_pair_accept_length_vs_oracle(hip):
                                                    top_p=0.9, details=True, noise=PhiloxOracleNoise(hip.lib, 55, 4, _st))
             assert abs(float(np.mean(wd["acc_len"])) - means[-1]) <= 0.6, (wd["acc_len"], d["acc_len"])
     print("mean accept length per sigma:", means)
-    assert means[0] >= 3.5 and means[-1] <= 1.0
+    assert means[0] >= 3.0 and means[-1] <= 1.0             # (the 68m -> 13b pair of bench.py reaches 3.76 at sigma = 0)
     assert all(means[i] >= means[i + 1] - 0.3 for i in range(len(means) - 1))
 
 
