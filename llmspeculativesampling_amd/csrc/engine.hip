@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "model_kernels.h"
+#include "small_kernels.h"
 
 static thread_local char g_err[512] = "";
 void sd_set_error(const char *fmt, ...) {
@@ -35,6 +36,10 @@ struct sd_session {
     char *scratch;
     // carved scratch
     void *x, *h, *qbuf, *attn, *act, *ebuf;
+    void *x2;           // second residual-stream buffer of the small-model path (the prologue-fused chain ping-pongs)
+    float *spart;       // split-K slabs of the small-model path's O / down GEMMs (its head writes s->part meanwhile)
+    size_t spart_floats;
+    float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
     float *attn_part;   // [groups*splits <= 64][Hq][TQ][D+2] partial attention sums of the split-key path
     float *part;
     size_t part_floats;
@@ -44,6 +49,11 @@ struct sd_session {
     const float *last_logits;
     long last_logits_ld;
     int last_logits_round;
+    // ... and with head_zero_rows set the head also leaves its tile maxima (last_tile_max, NULL when it could not) and
+    // clears the probability rows head_zero_rows + i * head_zero_ld of its logit rows (see EPI_HEAD)
+    float *head_zero_rows;
+    long head_zero_ld;
+    const float *last_tile_max;
     // profiling
     int prof_on;
     std::vector<hipEvent_t> ev_pool;
@@ -232,7 +242,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, h, q, attn, act, e, apart, part, total, part_floats;
+    size_t x, x2, h, q, attn, act, e, apart, part, spart, tmax, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -243,6 +253,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t trows = align_up(rows, 16);                     // GEMM operands live in 16-row tiles (xoff)
     p.x = take((size_t)rows * c.hidden * es);
+    p.x2 = take((size_t)SMALL_MAX_ROWS * c.hidden * es);
     p.h = take(trows * wide * es);
     p.q = take((size_t)rows * c.hidden * es);
     p.attn = take(trows * c.hidden * es);
@@ -261,6 +272,10 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     }
     p.part_floats = pf;
     p.part = take(pf * sizeof(float));
+    // small-model path: slabs [S][16][hidden] of its O / down GEMMs, S <= 16
+    p.spart_floats = (size_t)16 * 16 * c.hidden;
+    p.spart = take(p.spart_floats * sizeof(float));
+    p.tmax = take((size_t)SD_MAX_ROWS * (c.vocab / 16 + 1) * sizeof(float));
     p.total = off;
     return p;
 }
@@ -300,6 +315,13 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->scratch = (char *)scratch;
     const ScratchPlan p = plan_scratch(m->cfg, max_rows);
     s->x = s->scratch + p.x;
+    s->x2 = s->scratch + p.x2;
+    s->spart = (float *)(s->scratch + p.spart);
+    s->spart_floats = p.spart_floats;
+    s->tile_max = (float *)(s->scratch + p.tmax);
+    s->head_zero_rows = nullptr;
+    s->head_zero_ld = 0;
+    s->last_tile_max = nullptr;
     s->h = s->scratch + p.h;
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
@@ -501,12 +523,166 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
     return SD_OK;
 }
 
+
+// ---- small-model decode path (small_kernels.h): 5 launches per layer + the head --------------------------------
+static bool small_path_ok(const sd_session *s, const RowTab &tab) {
+    const sd_model_config &c = s->m->cfg;
+    const char *env = getenv("SD_SMALL_PATH");                         // (read per call: the tests flip it in-process)
+    const int enabled = env ? atoi(env) : 1;
+    if (!enabled || c.dtype != SD_BF16 || !c.fused_layout || tab.contig) return false;
+    if (tab.n_rows > SMALL_MAX_ROWS || tab.n_logit_rows > SMALL_MAX_ROWS) return false;
+    if (c.hidden > 2048 || c.hidden % 32 != 0 || embed_dim(c) != c.hidden) return false;
+    if (c.arch == SD_ARCH_OPT && !c.opt_pre_ln) return false;          // post-LN keeps the stand-alone norm launches
+    if (!s->m->w.final_norm_w) return false;
+    return true;
+}
+
+// k-slabs of the small path's O / down GEMMs.  Default: the streaming GEMM's own policy (bit-identical slabs, what the
+// parity tests compare against); SD_SMALL_SPLIT_BYTES = b cuts them so that a workgroup streams about b bytes.
+static void small_split(int N, int K, int *S_out, int *ksp_out) {
+    const char *env = getenv("SD_SMALL_SPLIT_BYTES");
+    const int bytes = env ? atoi(env) : 0;
+    const int KS = K / 32;
+    if (bytes <= 0) { gemm_split(N, K, 1, S_out, ksp_out); }
+    else {
+        int S = std::max(1, std::min(16, (int)((K * 32 + bytes / 2) / bytes)));
+        int ksp = (KS + S - 1) / S;
+        *S_out = (KS + ksp - 1) / ksp;
+        *ksp_out = ksp;
+    }
+    if (*S_out > 16) { *ksp_out = (KS + 15) / 16; *S_out = (KS + *ksp_out - 1) / *ksp_out; }
+}
+
+template <int PRO, int EPI>
+static int launch_small(sd_session *s, const void *W, const void *X, float *part, int M, int N, int K, int S, int ksp,
+                        const GemmEpi &e, const SmallPro &p, hipStream_t st) {
+    ProfScope ps(s, PC_GEMM, st);
+    const size_t lds = PRO == PRO_TILED ? 0 : (size_t)M * (K + SMALL_XPAD) * sizeof(bf16_t);
+    hipLaunchKernelGGL((gemm_small<PRO, EPI>), dim3((N / 16) * S), dim3(256), lds, st, (const u32x4 *)W, (const bf16_t *)X,
+                       part, M, N, K, S, ksp, e, p);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+static int launch_attn_bf16(sd_session *s, const bf16_t *q, const RowTab &tab, int layer, bf16_t *out, int s_max,
+                            hipStream_t st);
+
+static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits, hipStream_t st) {
+    sd_model *m = s->m;
+    const sd_model_config &c = m->cfg;
+    const int H = c.hidden, D = c.head_dim, I = c.inter, L = c.n_layers, M = tab.n_rows, n_logits = tab.n_logit_rows;
+    const bool llama = c.arch == SD_ARCH_LLAMA;
+    const int norm_kind = llama ? NORM_RMS : NORM_LN;
+    const int rn_threads = (int)std::min<size_t>(1024, std::max<size_t>(64, align_up((H / 4 + RN_RG - 1) / RN_RG, 64)));
+    bf16_t *R[2] = {(bf16_t *)s->x, (bf16_t *)s->x2};
+    bf16_t *qb = (bf16_t *)s->qbuf, *at = (bf16_t *)s->attn, *ac = (bf16_t *)s->act;
+    int cur = 0;                                                   // R[cur] holds the residual stream
+    int rc;
+    int S_o, ksp_o, S_d, ksp_d;
+    small_split(H, H, &S_o, &ksp_o);
+    small_split(H, I, &S_d, &ksp_d);
+    SD_REQUIRE((size_t)std::max(S_o, S_d) * 16 * H <= s->spart_floats, "forward_small: slab buffer too small");
+
+    auto resid_pro = [&](int S, const bf16_t *bias, const void *nw, const void *nb, bool write_r) {
+        SmallPro p = {};
+        p.slab = s->spart; p.S = S; p.stride_s = (size_t)16 * H; p.bias = bias;
+        p.r_in = R[cur]; p.r_out = write_r ? R[cur ^ 1] : nullptr;
+        p.nw = (const bf16_t *)nw; p.nb = (const bf16_t *)nb; p.eps = c.norm_eps; p.kind = norm_kind; p.H = H;
+        p.rn_threads = rn_threads;
+        return p;
+    };
+
+    for (int l = 0; l < L; ++l) {
+        // ---- QKV: prologue = embedding (layer 0) or previous layer's down slabs + residual, then input norm
+        {
+            GemmEpi e = {};
+            e.out = qb; e.bias = (const bf16_t *)m->bqkv[l];
+            e.cos_t = (const bf16_t *)m->w.rope_cos; e.sin_t = (const bf16_t *)m->w.rope_sin;
+            e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.layer = l; e.tab = tab;
+            e.q_scale = 1.0f / sqrtf((float)D);
+            if (l == 0) {
+                SmallPro p = {};
+                p.embed = (const bf16_t *)m->w.embed; p.pos_embed = llama ? nullptr : (const bf16_t *)m->w.pos_embed;
+                p.pos_off = 2; p.vocab = c.vocab; p.r_out = R[cur];
+                p.nw = (const bf16_t *)m->n1w[0]; p.nb = (const bf16_t *)m->n1b[0]; p.eps = c.norm_eps; p.kind = norm_kind;
+                p.H = H; p.rn_threads = rn_threads;
+                rc = llama ? launch_small<PRO_EMBED, EPI_QKV_ROPE>(s, m->wqkv[l], nullptr, nullptr, M, qkv_cols(c), H, 1, H / 32, e, p, st)
+                           : launch_small<PRO_EMBED, EPI_QKV_PLAIN>(s, m->wqkv[l], nullptr, nullptr, M, qkv_cols(c), H, 1, H / 32, e, p, st);
+            } else {
+                const SmallPro p = resid_pro(S_d, (const bf16_t *)m->bfc2[l - 1], m->n1w[l], m->n1b[l], true);
+                rc = llama ? launch_small<PRO_RESID, EPI_QKV_ROPE>(s, m->wqkv[l], nullptr, nullptr, M, qkv_cols(c), H, 1, H / 32, e, p, st)
+                           : launch_small<PRO_RESID, EPI_QKV_PLAIN>(s, m->wqkv[l], nullptr, nullptr, M, qkv_cols(c), H, 1, H / 32, e, p, st);
+                cur ^= 1;
+            }
+            if (rc != SD_OK) return rc;
+        }
+        // ---- attention over the arena
+        {
+            ProfScope ps(s, PC_ATTN, st);
+            if ((rc = launch_attn_bf16(s, qb, tab, l, at, s_max, st)) != SD_OK) return rc;
+            SD_LAUNCH_CHECK();
+        }
+        // ---- O projection -> slabs
+        {
+            GemmEpi e = {};
+            SmallPro p = {};
+            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wo[l], at, s->spart, M, H, H, S_o, ksp_o, e, p, st)) != SD_OK) return rc;
+        }
+        // ---- gate/up (fc1): prologue = O slabs + residual + post-attention norm; epilogue = SiLU * up / ReLU
+        {
+            GemmEpi e = {};
+            e.out = ac; e.bias = (const bf16_t *)m->bfc1[l]; e.n_out = I;
+            const SmallPro p = resid_pro(S_o, (const bf16_t *)m->bo[l], m->n2w[l], m->n2b[l], true);
+            rc = llama ? launch_small<PRO_RESID, EPI_ACT_SILU>(s, m->wgu[l], nullptr, nullptr, M, gu_cols(c), H, 1, H / 32, e, p, st)
+                       : launch_small<PRO_RESID, EPI_ACT_RELU>(s, m->wgu[l], nullptr, nullptr, M, gu_cols(c), H, 1, H / 32, e, p, st);
+            if (rc != SD_OK) return rc;
+            cur ^= 1;
+        }
+        // ---- down projection (fc2) -> slabs
+        {
+            GemmEpi e = {};
+            SmallPro p = {};
+            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wdown[l], ac, s->spart, M, H, I, S_d, ksp_d, e, p, st)) != SD_OK) return rc;
+        }
+    }
+    s->last_tile_max = nullptr;
+    if (n_logits > 0) {
+        // ---- head: prologue = last down slabs + residual + final norm on the rows that need logits
+        GemmEpi e = {};
+        e.use_xmap = 1; e.tab = tab;
+        SmallPro p = resid_pro(S_d, (const bf16_t *)m->bfc2[L - 1], m->w.final_norm_w, m->w.final_norm_b, false);
+        const int round_t = c.logits_bf16_round || (!llama && c.dtype == SD_BF16);
+        SD_REQUIRE((size_t)16 * c.vocab <= s->part_floats, "forward_small: logits slab too small");
+        if (s->want_raw_logits && s->head_zero_rows && c.vocab % 16 == 0) {
+            e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
+            if ((rc = launch_small<PRO_RESID, EPI_HEAD>(s, m->w.lm_head, nullptr, s->part, n_logits, c.vocab, H, 1, H / 32, e, p, st)) != SD_OK) return rc;
+            s->last_tile_max = s->tile_max;
+        } else {
+            if ((rc = launch_small<PRO_RESID, EPI_PART>(s, m->w.lm_head, nullptr, s->part, n_logits, c.vocab, H, 1, H / 32, e, p, st)) != SD_OK) return rc;
+        }
+        if (s->want_raw_logits) {
+            s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
+        } else {
+            ProfScope ps(s, PC_LOGITS, st);
+            hipLaunchKernelGGL((logits_kernel<bf16_t>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, 1,
+                               (size_t)16 * c.vocab, c.vocab, round_t, logits_out, ld_logits);
+            SD_LAUNCH_CHECK();
+            s->last_logits = logits_out; s->last_logits_ld = ld_logits; s->last_logits_round = 0;
+        }
+    }
+    return SD_OK;
+}
+
 template <typename T>
 static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits,
                         hipStream_t st) {
     const int n_new = tab.n_rows, n_logits = tab.n_logit_rows;
     sd_model *m = s->m;
     const sd_model_config &c = m->cfg;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        if (small_path_ok(s, tab)) return forward_small(s, tab, s_max, logits_out, ld_logits, st);
+    }
+    s->last_tile_max = nullptr;
     const int H = c.hidden, D = c.head_dim, I = c.inter, L = c.n_layers, ED = embed_dim(c);
     const bool llama = c.arch == SD_ARCH_LLAMA;
     const int norm_kind = llama ? NORM_RMS : NORM_LN;
@@ -647,8 +823,24 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
             hl = eb;
         }
-        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
         const int round_t = c.logits_bf16_round || (!llama && c.dtype == SD_BF16);
+        // native iteration: the head also leaves the maximum of every 16-column tile and clears the probability rows, so
+        // the normalisation that follows needs no candidate pass over V (EPI_HEAD; whole k-range per workgroup)
+        if (c.dtype == SD_BF16 && s->want_raw_logits && s->head_zero_rows && n_logits <= 16 && c.vocab % 16 == 0 &&
+            gemm_plan(c.vocab, ED, n_logits, false).S == 1 && !gemm_plan(c.vocab, ED, n_logits, false).tiled) {
+            GemmEpi e = {};
+            if (xt) { e.use_xmap = 1; e.tab = *xt; }
+            e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
+            {
+                ProfScope ps(s, PC_GEMM, st);
+                launch_gemm_bf16<1, EPI_HEAD, 1>(m->w.lm_head, hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
+                SD_LAUNCH_CHECK();
+            }
+            s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
+            s->last_tile_max = s->tile_max;
+            return SD_OK;
+        }
+        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
         if (s->want_raw_logits && go.S == 1) {
             s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
         } else {
@@ -687,6 +879,16 @@ static void finish_table(RowTab &tab) {
         tab.grp_stream[tab.n_groups] = tab.row_stream[r];
         ++tab.n_groups;
         r += n;
+    }
+}
+
+static int launch_attn_bf16(sd_session *s, const bf16_t *q, const RowTab &tab, int layer, bf16_t *out, int s_max,
+                            hipStream_t st) {
+    switch (s->m->cfg.head_dim) {
+        case 16: return launch_attn<bf16_t, 16>(s, q, tab, layer, out, s_max, st);
+        case 32: return launch_attn<bf16_t, 32>(s, q, tab, layer, out, s_max, st);
+        case 64: return launch_attn<bf16_t, 64>(s, q, tab, layer, out, s_max, st);
+        default: return launch_attn<bf16_t, 128>(s, q, tab, layer, out, s_max, st);
     }
 }
 
@@ -893,6 +1095,11 @@ extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld,
                               const float *r, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *out,
                               void *stream);
 
+int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                            int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, uint64_t seed,
+                            uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
+                            void *stream);
+
 // feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows, all of them from the
 // final call (a chunk never ends inside the logits rows), so that call's output slab can be handed to the norm as is
 static int feed_rows(sd_session *ses, const int32_t *seq, int from, int upto, int n_logits, float *logits, long ld,
@@ -922,18 +1129,26 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     hipStream_t st = (hipStream_t)stream;
     const int g = sp->gamma, V = sp->V;
     int rc;
+    // EPI_HEAD's tile maxima serve the top-k candidate search only (1 <= k <= 64, positive temperature, 16 | V >= 4096)
+    const bool tiles_ok = sp->top_k >= 1 && sp->top_k <= 64 && sp->temperature > 0.0f && V % 16 == 0 && V >= 4096 &&
+                          V <= 65536 && sp->ld % 4 == 0 && (getenv("SD_HEAD_TILES") ? atoi(getenv("SD_HEAD_TILES")) : 1);
     if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[0], st));
     // ---- draft: gamma steps; the sampled token goes straight into seq[] where the next step's embed reads it
     for (int i = 0; i < g; ++i) {
         const int upto = L + i;
+        float *q_row = sp->q_hist + (size_t)(upto - 1) * sp->ld;
         sp->draft->want_raw_logits = 1;
+        sp->draft->head_zero_rows = tiles_ok ? q_row : nullptr;      // the head clears the row and leaves tile maxima
+        sp->draft->head_zero_ld = sp->ld;
         rc = feed_rows(sp->draft, sp->seq, draft_len, upto, 1, sp->draft_logits, sp->ld_dl, stream);
         sp->draft->want_raw_logits = 0;
+        sp->draft->head_zero_rows = nullptr;
         if (rc != SD_OK) return rc;
         draft_len = upto;
-        if ((rc = sd_norm_sample(sp->draft->last_logits, V, sp->temperature, sp->top_k, sp->top_p, sp->draft->last_logits_round,
-                                 sp->q_hist + (size_t)(upto - 1) * sp->ld, sp->err + i, nullptr, seed_draft,
-                                 draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws, stream)) != SD_OK)
+        if ((rc = sd_norm_rows_with_tiles(sp->draft->last_logits, 1, V, sp->draft->last_logits_ld, sp->temperature, sp->top_k,
+                                          sp->top_p, sp->draft->last_logits_round, q_row, sp->ld, sp->err + i, seed_draft,
+                                          draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws,
+                                          sp->draft->last_tile_max, stream)) != SD_OK)
             return rc;
     }
     if (sp->timing) { SD_HIP_CHECK(hipEventRecord(sp->ev[1], st)); SD_HIP_CHECK(hipEventRecord(sp->ev[2], st)); }
@@ -941,13 +1156,17 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     {
         const int upto = L + g;
         const int rows = std::min(upto - target_len, g + 1);
+        float *p_rows = sp->p_hist + (size_t)(upto - rows) * sp->ld;
         sp->target->want_raw_logits = 1;
+        sp->target->head_zero_rows = tiles_ok ? p_rows : nullptr;
+        sp->target->head_zero_ld = sp->ld;
         rc = feed_rows(sp->target, sp->seq, target_len, upto, rows, sp->target_logits, sp->ld_tl, stream);
         sp->target->want_raw_logits = 0;
+        sp->target->head_zero_rows = nullptr;
         if (rc != SD_OK) return rc;
-        if ((rc = sd_norm_probs(sp->target->last_logits, rows, V, sp->target->last_logits_ld, sp->temperature, sp->top_k, sp->top_p,
-                                sp->target->last_logits_round,
-                                sp->p_hist + (size_t)(upto - rows) * sp->ld, sp->ld, sp->err + 2 * g, sp->norm_ws, stream)) != SD_OK)
+        if ((rc = sd_norm_rows_with_tiles(sp->target->last_logits, rows, V, sp->target->last_logits_ld, sp->temperature,
+                                          sp->top_k, sp->top_p, sp->target->last_logits_round, p_rows, sp->ld, sp->err + 2 * g,
+                                          0, 0, nullptr, nullptr, sp->norm_ws, sp->target->last_tile_max, stream)) != SD_OK)
             return rc;
     }
     if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[3], st));

@@ -56,7 +56,7 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 // The MFMA runs with A = W tile (rows n), B = X^T (cols m): lane holds D[n = 4*(lane>>4)+j][m = lane&15],
 // so each lane stores 4 consecutive n as one float4.
 // ------------------------------------------------------------------------------------------
-enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4 };
+enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4, EPI_HEAD = 5 };
 
 // Arguments of the fused epilogues (SB == 1: the workgroup holds the whole dot product after its LDS fold).
 struct GemmEpi {
@@ -68,12 +68,121 @@ struct GemmEpi {
     float q_scale;
     int use_xmap;             // lm_head: activation row m is tab.xmap[m] of X
     int x_rowmajor;           // X is plain [M][K] rows (the public sd_gemm_bf16 entry) instead of the tile layout
+    // EPI_HEAD (lm_head, whole k-range per workgroup): besides the logits slab, the maximum of every 16-column tile
+    // (NaN if the tile holds one) goes to tile_max[m][N/16] and the tile's 16 entries of the probability row
+    // zero_rows + m * zero_ld are cleared - what the sampler needs to pick its top-k candidates without a pass over V
+    float *tile_max;
+    float *zero_rows;
+    long zero_ld;
     RowTab tab;
 };
 
 __device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, float d) {
     const bf16_t v[4] = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
+}
+
+// One fold step of the streaming GEMMs' epilogue: red[wave][pp][lane] holds the 4 waves' accumulators of PT tiles; the
+// folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
+// gemm_small (small_kernels.h).
+template <int MT, int EPI, int NTW, int PT>
+__device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
+                                                   int N, int sb, int ntg, const GemmEpi &e) {
+    auto folded = [&](int pp, int l) -> f32x4 {
+        return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
+    };
+    if constexpr (EPI == EPI_PART) {
+        if (threadIdx.x < PT * 64) {
+            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+            const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
+            if (m < M)
+                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(pp, l);
+        }
+    } else if constexpr (EPI == EPI_HEAD) {
+        static_assert(EPI != EPI_HEAD || (MT == 1 && NTW == 1 && PT == 1), "EPI_HEAD: one 16-row tile, one n-tile per workgroup");
+        if (threadIdx.x < 64) {                                   // one whole wave: lanes l, l^16, l^32, l^48 share row m
+            const int l = threadIdx.x, m = l & 15, nt = ntg;
+            const f32x4 r = folded(0, l);
+            float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+            int bad = (r[0] != r[0]) | (r[1] != r[1]) | (r[2] != r[2]) | (r[3] != r[3]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); bad |= __shfl_xor(bad, 16, 64);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); bad |= __shfl_xor(bad, 32, 64);
+            if (m < M) {
+                *reinterpret_cast<f32x4 *>(part + (size_t)m * N + nt * 16 + (l >> 4) * 4) = r;
+                if (e.zero_rows)
+                    *reinterpret_cast<f32x4 *>(e.zero_rows + (size_t)m * e.zero_ld + nt * 16 + (l >> 4) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (l < 16) e.tile_max[(size_t)m * (N >> 4) + nt] = bad ? __uint_as_float(0x7fc00000u) : mx;
+            }
+        }
+    } else if constexpr (EPI == EPI_ACT_SILU) {
+        // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
+        if (threadIdx.x < PT * 32) {
+            const int pp = threadIdx.x >> 5, l = threadIdx.x & 31, q = fs * PT + pp;
+            const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
+            if (m < M) {
+                const f32x4 g = folded(pp, l), u = folded(pp, l + 32);
+                float a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float gj = rnd<bf16_t>(g[c]), uj = rnd<bf16_t>(u[c]);
+                    a[c] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                }
+                store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
+            }
+        }
+    } else if constexpr (EPI == EPI_ACT_RELU) {
+        if (threadIdx.x < PT * 64) {
+            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+            const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
+            if (m < M) {
+                const f32x4 r = folded(pp, l);
+                float a[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float f = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                    a[c] = f > 0.f ? f : 0.f;
+                }
+                store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
+            }
+        }
+    } else {
+        // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
+        // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
+        const int hd = e.D >> 1;
+        if (threadIdx.x < PT * 64) {
+            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+            const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
+            if (m < M) {
+                const f32x4 r = folded(pp, l);
+                const int head = col / e.D, within = col - head * e.D;
+                const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
+                const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
+                bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
+                bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
+                                   : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
+                                           : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
+                float x[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int d = (within >> 1) + pr;
+                        const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
+                        const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
+                        dst[d] = (bf16_t)(rnd<bf16_t>(x0 * cs) + rnd<bf16_t>(-x1 * sn));
+                        dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * cs) + rnd<bf16_t>(x0 * sn));
+                    }
+                } else {
+                    if (EPI == EPI_QKV_PLAIN && is_q) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(x[c] * e.q_scale);
+                    }
+                    store4(dst + within, x[0], x[1], x[2], x[3]);
+                }
+            }
+        }
+    }
 }
 
 template <int MT, int UNROLL, int EPI, int NTW, bool NT_LOADS = true>
@@ -161,85 +270,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) red[wv][pp][lane] = acc[(fs * PT + pp) / MT][(fs * PT + pp) % MT];
         __syncthreads();
-        auto folded = [&](int pp, int l) -> f32x4 {
-            return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
-        };
-        if constexpr (EPI == EPI_PART) {
-            if (threadIdx.x < PT * 64) {
-                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
-                const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
-                if (m < M)
-                    *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(pp, l);
-            }
-        } else if constexpr (EPI == EPI_ACT_SILU) {
-            // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
-            if (threadIdx.x < PT * 32) {
-                const int pp = threadIdx.x >> 5, l = threadIdx.x & 31, q = fs * PT + pp;
-                const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
-                if (m < M) {
-                    const f32x4 g = folded(pp, l), u = folded(pp, l + 32);
-                    float a[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float gj = rnd<bf16_t>(g[c]), uj = rnd<bf16_t>(u[c]);
-                        a[c] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
-                    }
-                    store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
-                }
-            }
-        } else if constexpr (EPI == EPI_ACT_RELU) {
-            if (threadIdx.x < PT * 64) {
-                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
-                const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
-                if (m < M) {
-                    const f32x4 r = folded(pp, l);
-                    float a[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float f = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
-                        a[c] = f > 0.f ? f : 0.f;
-                    }
-                    store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
-                }
-            }
-        } else {
-            // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
-            // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
-            const int hd = e.D >> 1;
-            if (threadIdx.x < PT * 64) {
-                const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
-                const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
-                if (m < M) {
-                    const f32x4 r = folded(pp, l);
-                    const int head = col / e.D, within = col - head * e.D;
-                    const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
-                    const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
-                    bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
-                    bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
-                                       : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
-                                               : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
-                    float x[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
-                    if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            const int d = (within >> 1) + pr;
-                            const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
-                            const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
-                            dst[d] = (bf16_t)(rnd<bf16_t>(x0 * cs) + rnd<bf16_t>(-x1 * sn));
-                            dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * cs) + rnd<bf16_t>(x0 * sn));
-                        }
-                    } else {
-                        if (EPI == EPI_QKV_PLAIN && is_q) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(x[c] * e.q_scale);
-                        }
-                        store4(dst + within, x[0], x[1], x[2], x[3]);
-                    }
-                }
-            }
-        }
+        gemm_epilogue_step<MT, EPI, NTW, PT>(red, fs, part, M, Mpad, N, sb, ntg, e);
     }
 }
 

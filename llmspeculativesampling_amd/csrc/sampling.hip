@@ -273,7 +273,11 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                                                        int *__restrict__ err, const float *__restrict__ noise,
                                                        uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
                                                        int *__restrict__ samp_err, const CandRow *__restrict__ ws,
-                                                       NormTab tab, int use_tab, int filter_only) {
+                                                       NormTab tab, int use_tab, int filter_only,
+                                                       const float *__restrict__ tile_max) {
+    // tile_max (or NULL): the lm_head's epilogue (EPI_HEAD, model_kernels.h) left the maximum of every 16-column tile
+    // of the logits row (NaN when the tile holds one) in tile_max[row][V/16] and cleared the output row; the candidates
+    // for 1 <= top_k <= 64 are then found from V/16 maxima + the few tiles that can hold one, without a pass over V.
     // filter_only: write top_k_top_p_filter's result (utils.py:152-179) - the scaled logit where kept, -inf where
     // dropped - instead of the probabilities (the kept set itself, not "probability > 0", which underflow would shrink)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -372,6 +376,73 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             m = mx;
         } else {
             bad = 0;
+        }
+    } else if (tile_max) {
+        const int NTL = V >> 4;
+        const float *tm = tile_max + (size_t)row * NTL;
+        constexpr int TPT = 4;                                    // tiles per thread (V <= 65536)
+        float zt[TPT];
+        float mtl = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int t = tid + u * NT;
+            zt[u] = -INFINITY;
+            if (t < NTL) {
+                float v = tm[t];
+                bad |= (v != v);
+                if (bf16_round) v = (float)(bf16_t)v;
+                v = v / temperature;                              // temperature > 0: monotone, max commutes with it
+                zt[u] = v;
+                mtl = fmaxf(mtl, v);
+            }
+        }
+        m = block_max(mtl, S.redf);
+        bad = block_sum_i(bad, S.redi);
+        if (!bad && m != INFINITY && m != -INFINITY) {
+            // threshold t0 = the largest, over the 16 waves, of the wave's k-th largest per-thread maximum: at least k
+            // tiles - hence k elements - lie at or above it, and every element >= t0 sits in a tile whose maximum is
+            const int k = min(top_k, V);
+            const uint32_t mk = fkey(mtl);
+            int rank = 0;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) {
+                const uint32_t kj = (uint32_t)__shfl((int)mk, j, 64);
+                rank += (kj > mk) || (kj == mk && j < lane);
+            }
+            const unsigned long long hit = __ballot(rank == k - 1);
+            const uint32_t wk = (uint32_t)__shfl((int)mk, hit ? (int)(__ffsll((long long)hit) - 1) : 0, 64);
+            __syncthreads();
+            if (lane == 0) S.redu[wv] = wk;
+            if (tid == 0) S.n_cand = 0;
+            __syncthreads();
+            uint32_t t0 = S.redu[0];
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) t0 = max(t0, S.redu[i]);
+#pragma unroll
+            for (int u = 0; u < TPT; ++u) {
+                const int t = tid + u * NT;
+                if (t < NTL && fkey(zt[u]) >= t0) {
+                    float4 q4[4];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) q4[c4] = reinterpret_cast<const float4 *>(x + (size_t)t * 16)[c4];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float ev4[4] = {q4[c4].x, q4[c4].y, q4[c4].z, q4[c4].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = ev4[c];
+                            if (bf16_round) v = (float)(bf16_t)v;
+                            const uint32_t kk = fkey(v / temperature);
+                            if (kk >= t0) {
+                                const int slot = atomicAdd(&S.n_cand, 1);
+                                if (slot < MAX_CAND) { S.ckey[slot] = kk; S.cidx[slot] = t * 16 + c4 * 4 + c; }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (S.n_cand <= MAX_CAND) fast = true;               // else pathological ties: the general path below
         }
     }
     STAMP(1);
@@ -499,6 +570,15 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     int cut_idx = 0x7fffffff;
     int kept = -1;                                                // >= 0: the kept set is skey/sidx[0..kept)
     if (have_list) kept = n_surv;
+    // exp(z_i - m) of the sorted survivors, one per thread (the candidate arrays are free after the sort); the serial
+    // sums below then only add, in the same order as before
+    float *ev = reinterpret_cast<float *>(S.ckey);
+    auto fill_ev = [&](int n) {
+        __syncthreads();
+        if (tid < n) ev[tid] = expf(funkey(S.skey[tid]) - m);
+        __syncthreads();
+    };
+    if (have_list) fill_ev(n_surv);
     if (top_p > 0.0f) {
         if (!have_list) {
             int c = 0;
@@ -523,6 +603,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 rank_sort(S, S.n_cand);
                 n_surv = S.n_cand;
                 have_list = true;
+                fill_ev(n_surv);
             }
         }
         if (have_list) {
@@ -531,13 +612,13 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 int nf = n_surv;
                 while (nf > 1 && S.skey[nf - 1] <= neg_inf_key) --nf;
                 float denom = 0.f;                                // softmax denominator over the survivors
-                for (int i = 0; i < nf; ++i) denom += expf(funkey(S.skey[i]) - m);
+                for (int i = 0; i < nf; ++i) denom += ev[i];
                 // torch.cumsum accumulates float32 inputs in double and rounds each prefix to float32
                 double cum = 0.0;
                 int kp = 0;
                 for (int i = 0; i < nf; ++i) {
                     if (i > 0 && (float)cum > top_p) break;       // shifted filter: the crossing token stays
-                    cum += (double)(expf(funkey(S.skey[i]) - m) / denom);
+                    cum += (double)(ev[i] / denom);
                     kp = i + 1;
                 }
                 S.kept = kp;
@@ -617,7 +698,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         // list mode: the kept set is the first `kept` entries of the sorted candidate list
         if (tid == 0) {
             float sum = 0.f;
-            for (int i = 0; i < kept; ++i) sum += expf(funkey(S.skey[i]) - m);
+            for (int i = 0; i < kept; ++i) sum += ev[i];
             S.lse = logf(sum);
         }
         const float fillv = filter_only ? -INFINITY : 0.f;
@@ -977,7 +1058,8 @@ extern "C" int sd_philox_uniform(uint64_t seed, uint64_t draw_index, int n, floa
 static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
                        const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
-                       void *stream, const NormTab *tabp = nullptr, int filter_only = 0) {
+                       void *stream, const NormTab *tabp = nullptr, int filter_only = 0,
+                       const float *tile_max = nullptr) {
     NormTab tab = {};
     const int use_tab = tabp != nullptr;
     if (tabp) tab = *tabp;
@@ -992,9 +1074,13 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    // the head already left tile maxima and a cleared output row (EPI_HEAD): no candidate pass over V at all
+    if (tile_max && !(top_k >= 1 && top_k <= 64 && temperature > 0.0f && (V & 15) == 0 && V >= 4096 && V <= 65536 &&
+                      (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && !use_tab && !filter_only))
+        tile_max = nullptr;
     // two-kernel fast path: the row is cut over NB_SPLIT workgroups first (see norm_cand_kernel)
     CandRow *ws = nullptr;
-    if (workspace && top_k >= 1 && top_k <= 64 && V >= 4096 && (V & 3) == 0 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
+    if (!tile_max && workspace && top_k >= 1 && top_k <= 64 && V >= 4096 && (V & 3) == 0 && (ld_in & 3) == 0 && (ld_out & 3) == 0 &&
         ((V >> 2) + NB_SPLIT - 1) / NB_SPLIT <= 256 * CAND_MAXIT && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
         (use_tab || (reinterpret_cast<uintptr_t>(probs_out) & 15) == 0)) {
         ws = static_cast<CandRow *>(workspace);
@@ -1005,14 +1091,24 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
     if (do_sample)
         hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
-                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0);
+                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0, tile_max);
     else
         hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
                            (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
-                           (const CandRow *)ws, tab, use_tab, filter_only);
+                           (const CandRow *)ws, tab, use_tab, filter_only, tile_max);
     SD_LAUNCH_CHECK();
     return SD_OK;
+}
+
+// internal (engine.hip, sd_spec_iteration): norm_logits of `rows` logit rows whose head left tile maxima (or NULL) and
+// cleared probs_out; with tok_out != NULL also the sample that follows a draft step (rows == 1)
+int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                            int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, uint64_t seed,
+                            uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
+                            void *stream) {
+    return launch_norm(logits, rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, probs_out, ld_out, err_flag,
+                       tok_out != nullptr, nullptr, seed, draw, tok_out, samp_err, workspace, stream, nullptr, 0, tile_max);
 }
 
 // top_k_top_p_filter on its own (utils.py:152-179): out = logit where kept, -inf where dropped (out != logits).

@@ -418,3 +418,45 @@ def test_top_k_top_p_filter_in_place_and_support(hip):
     assert sorted(torch.nonzero(torch.isfinite(w[0])).flatten().tolist()) == [3, 9, 11]
     ow = oracle.top_k_top_p_filter(z.cpu(), 3, 0.0)
     assert torch.equal(torch.isfinite(w.cpu()), torch.isfinite(ow))
+
+
+# --------------------------------------------------------------------------- small-model decode path (small_kernels.h)
+SMALL_CFGS = {
+    "llama68m_like": dict(arch="llama", vocab_size=8192, hidden_size=768, intermediate_size=3072, num_hidden_layers=2,
+                          num_attention_heads=12, num_key_value_heads=12, max_position_embeddings=256, rms_norm_eps=1e-6),
+    "llama_gqa_h256": dict(arch="llama", vocab_size=4096, hidden_size=256, intermediate_size=704, num_hidden_layers=3,
+                           num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5),
+    "opt125m_like": dict(arch="opt", vocab_size=8192, hidden_size=768, ffn_dim=3072, num_hidden_layers=2,
+                         num_attention_heads=12, max_position_embeddings=256, do_layer_norm_before=True,
+                         word_embed_proj_dim=768),
+}
+
+
+@pytest.mark.parametrize("name", list(SMALL_CFGS))
+def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name):
+    """The prologue-fused decode chain for small models (5 launches per layer; norm + residual recomputed inside the
+    consuming GEMM) must give bit-identical logits and KV rows to the per-op chain (SD_SMALL_PATH=0) for 1..4 new rows,
+    and both must agree with the oracle forward in bf16."""
+    cfg = ModelConfig(**SMALL_CFGS[name])
+    sd = make_state_dict(cfg, 90, dtype=torch.bfloat16)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.bfloat16)
+    ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 40))).to(torch.int32).cuda()[0]
+    outs = {}
+    for flag in ("1", "0"):
+        os.environ["SD_SMALL_PATH"] = flag
+        try:
+            ses = m.new_session(64)
+            ses.forward(ids[:30], 0)                              # prompt (many rows: the per-op chain either way)
+            got, pos = [], 30
+            for q in (1, 2, 1, 4, 3):
+                got.append(ses.forward(ids[pos:pos + q], q).clone())
+                pos += q
+            outs[flag] = (torch.cat(got), ses.kv[:, :, :, :pos].clone())
+        finally:
+            os.environ.pop("SD_SMALL_PATH", None)
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])
+    om = oracle.RefCausalLM(cfg, sd)
+    want = om(ids[None].long().cpu()).logits.float()[0, 30:41]
+    got = outs["1"][0].cpu()
+    assert float((got - want[: got.shape[0]]).abs().max()) <= 0.04 * float(want.abs().max())
