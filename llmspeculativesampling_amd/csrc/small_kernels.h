@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, 
     // the weights do not depend on the prologue: request this wave's first KSW tiles now
     u32x4 w[KSW];
 #pragma unroll
-    for (int u = 0; u < KSW; ++u)
-        if (ks0 + u < ks1) w[u] = wp[(size_t)u * 64];
+    for (int u = 0; u < KSW; ++u) w[u] = ks0 + u < ks1 ? __builtin_nontemporal_load(wp + (size_t)u * 64) : u32x4{0u, 0u, 0u, 0u};
 
     if constexpr (PRO == PRO_EMBED) {
         // embed_norm_kernel's arithmetic: thread t owns columns t, t + 256, ...
@@ -180,11 +179,12 @@ __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, 
         if (base != ks0) {
 #pragma unroll
             for (int u = 0; u < KSW; ++u)
-                if (base + u < ks1) w[u] = wp[(size_t)(base - ks0 + u) * 64];
+                if (base + u < ks1) w[u] = __builtin_nontemporal_load(wp + (size_t)(base - ks0 + u) * 64);
         }
         u32x4 x[KSW];
 #pragma unroll
         for (int u = 0; u < KSW; ++u) {
+            x[u] = u32x4{0u, 0u, 0u, 0u};
             if (base + u < ks1) {
                 if constexpr (PRO == PRO_TILED)
                     x[u] = mv ? *reinterpret_cast<const u32x4 *>(xg + (size_t)(base - ks0 + u) * 512) : u32x4{0u, 0u, 0u, 0u};

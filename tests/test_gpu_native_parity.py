@@ -422,11 +422,11 @@ def test_top_k_top_p_filter_in_place_and_support(hip):
 
 # --------------------------------------------------------------------------- small-model decode path (small_kernels.h)
 SMALL_CFGS = {
-    "llama68m_like": dict(arch="llama", vocab_size=8192, hidden_size=768, intermediate_size=3072, num_hidden_layers=2,
+    "llama68m_like": dict(arch="llama", vocab_size=16384, hidden_size=768, intermediate_size=3072, num_hidden_layers=2,
                           num_attention_heads=12, num_key_value_heads=12, max_position_embeddings=256, rms_norm_eps=1e-6),
-    "llama_gqa_h256": dict(arch="llama", vocab_size=4096, hidden_size=256, intermediate_size=704, num_hidden_layers=3,
+    "llama_gqa_h256": dict(arch="llama", vocab_size=16384, hidden_size=256, intermediate_size=704, num_hidden_layers=3,
                            num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5),
-    "opt125m_like": dict(arch="opt", vocab_size=8192, hidden_size=768, ffn_dim=3072, num_hidden_layers=2,
+    "opt125m_like": dict(arch="opt", vocab_size=16384, hidden_size=768, ffn_dim=3072, num_hidden_layers=2,
                          num_attention_heads=12, max_position_embeddings=256, do_layer_norm_before=True,
                          word_embed_proj_dim=768),
 }
@@ -436,11 +436,12 @@ SMALL_CFGS = {
 def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name):
     """The prologue-fused decode chain for small models (5 launches per layer; norm + residual recomputed inside the
     consuming GEMM) must give bit-identical logits and KV rows to the per-op chain (SD_SMALL_PATH=0) for 1..4 new rows,
-    and both must agree with the oracle forward in bf16."""
+    and both must agree with the oracle forward in bf16.  (Vocabulary 16384: from 1024 n-tiles on, the per-op chain's
+    head also keeps the whole k-range in one workgroup; below that it sums two k-slabs and differs in the last fp32 bit.)"""
     cfg = ModelConfig(**SMALL_CFGS[name])
     sd = make_state_dict(cfg, 90, dtype=torch.bfloat16)
     m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.bfloat16)
-    ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 40))).to(torch.int32).cuda()[0]
+    ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 41))).to(torch.int32).cuda()[0]
     outs = {}
     for flag in ("1", "0"):
         os.environ["SD_SMALL_PATH"] = flag
