@@ -7,6 +7,7 @@
 // One workgroup of 1024 threads (16 waves) owns one vocabulary row: the row is staged once in
 // LDS (V*4 B <= 128 KiB for Llama's V = 32000) and every later pass reads LDS, not HBM.
 #include "common.h"
+#include <stdlib.h>
 
 #ifdef SD_STAMPS
 __device__ long long g_stamps[32];
@@ -80,8 +81,8 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *sh) {
     if (lane == 0) sh[w] = a;
     __syncthreads();
     ArgMax r = sh[0];
-#pragma unroll
-    for (int i = 1; i < NT / 64; ++i) r = am_better(r, sh[i]);
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 1; i < nw; ++i) r = am_better(r, sh[i]);
     return r;
 }
 
@@ -136,8 +137,7 @@ struct NormShared {
 
 // Stable descending order of the n (<= MAX_CAND) candidates in ckey/cidx by rank counting -> skey/sidx.
 __device__ __forceinline__ void rank_sort(NormShared &S, int n) {
-    const int tid = threadIdx.x;
-    if (tid < n) {
+    for (int tid = threadIdx.x; tid < n; tid += blockDim.x) {
         const uint32_t k = S.ckey[tid];
         const int id = S.cidx[tid];
         int rank = 0;
@@ -158,6 +158,21 @@ __device__ __forceinline__ void rank_sort(NormShared &S, int n) {
         S.sidx[rank] = id;
     }
     __syncthreads();
+}
+
+// k-th largest (k = 1..64) of the 64 lanes' keys, ties broken by lane: every lane gets it.  v_readlane with a constant
+// lane index instead of __shfl (ds_bpermute through the LDS crossbar, ~100 cycles each, 64 of them in a row).
+__device__ __forceinline__ uint32_t wave_kth_largest(uint32_t mk, int k) {
+    const int lane = threadIdx.x & 63;
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)mk, j);
+        rank += (kj > mk) || (kj == mk && j < lane);
+    }
+    const unsigned long long hit = __ballot(rank == k - 1);
+    const int src = hit ? (int)(__ffsll((long long)hit) - 1) : 0;
+    return (uint32_t)__shfl((int)mk, src, 64);
 }
 
 // ---- multi-workgroup candidate extraction (fast path, 1 <= top_k <= 64) -------------------------------
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     NormShared &S = *reinterpret_cast<NormShared *>(smem);
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int NTX = blockDim.x, NWX = NTX >> 6;         // 1024 threads, or 256 when the head left tile maxima
     const float *x = logits + (size_t)row * ld_in;
     float *o = use_tab ? tab.out[blockIdx.x] : out + (size_t)row * ld_out;
     int *errp = use_tab ? tab.err[blockIdx.x] : (err ? err + row : nullptr);
@@ -359,8 +375,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 if (lane == 0) S.redu[wv] = wk;
                 __syncthreads();
                 uint32_t t1 = S.redu[0];
-#pragma unroll
-                for (int i = 1; i < NT / 64; ++i) t1 = max(t1, S.redu[i]);
+                for (int i = 1; i < NWX; ++i) t1 = max(t1, S.redu[i]);
                 if (tid < tot && mk >= t1) {
                     const int slot = atomicAdd(&S.kept, 1);
                     S.skey[slot] = mk;
@@ -380,12 +395,12 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     } else if (tile_max) {
         const int NTL = V >> 4;
         const float *tm = tile_max + (size_t)row * NTL;
-        constexpr int TPT = 4;                                    // tiles per thread (V <= 65536)
+        constexpr int TPT = 16;                                   // tiles per thread at 256 threads (V <= 65536)
         float zt[TPT];
         float mtl = -INFINITY;
 #pragma unroll
         for (int u = 0; u < TPT; ++u) {
-            const int t = tid + u * NT;
+            const int t = tid + u * NTX;
             zt[u] = -INFINITY;
             if (t < NTL) {
                 float v = tm[t];
@@ -402,44 +417,43 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             // threshold t0 = the largest, over the 16 waves, of the wave's k-th largest per-thread maximum: at least k
             // tiles - hence k elements - lie at or above it, and every element >= t0 sits in a tile whose maximum is
             const int k = min(top_k, V);
-            const uint32_t mk = fkey(mtl);
-            int rank = 0;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) {
-                const uint32_t kj = (uint32_t)__shfl((int)mk, j, 64);
-                rank += (kj > mk) || (kj == mk && j < lane);
-            }
-            const unsigned long long hit = __ballot(rank == k - 1);
-            const uint32_t wk = (uint32_t)__shfl((int)mk, hit ? (int)(__ffsll((long long)hit) - 1) : 0, 64);
+            const uint32_t wk = wave_kth_largest(fkey(mtl), k);
             __syncthreads();
             if (lane == 0) S.redu[wv] = wk;
             if (tid == 0) S.n_cand = 0;
             __syncthreads();
             uint32_t t0 = S.redu[0];
-#pragma unroll
-            for (int i = 1; i < NT / 64; ++i) t0 = max(t0, S.redu[i]);
+            for (int i = 1; i < NWX; ++i) t0 = max(t0, S.redu[i]);
+            // the tiles that can hold a candidate are first compacted into a list (no memory traffic), then their
+            // 16 logits each are read by 16 consecutive threads, all tiles in flight at once: a thread walking its own
+            // tiles would pay one dependent global round trip per tile, with the whole wave waiting on any lane's
+            int *tlist = S.sidx;                                  // (the sorted-list arrays are free until rank_sort)
+            int *tcount = &S.kept;
+            if (tid == 0) *tcount = 0;
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < TPT; ++u) {
-                const int t = tid + u * NT;
+                const int t = tid + u * NTX;
                 if (t < NTL && fkey(zt[u]) >= t0) {
-                    float4 q4[4];
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) q4[c4] = reinterpret_cast<const float4 *>(x + (size_t)t * 16)[c4];
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float ev4[4] = {q4[c4].x, q4[c4].y, q4[c4].z, q4[c4].w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            float v = ev4[c];
-                            if (bf16_round) v = (float)(bf16_t)v;
-                            const uint32_t kk = fkey(v / temperature);
-                            if (kk >= t0) {
-                                const int slot = atomicAdd(&S.n_cand, 1);
-                                if (slot < MAX_CAND) { S.ckey[slot] = kk; S.cidx[slot] = t * 16 + c4 * 4 + c; }
-                            }
-                        }
+                    const int slot = atomicAdd(tcount, 1);
+                    if (slot < MAX_CAND) tlist[slot] = t;
+                }
+            }
+            __syncthreads();
+            const int ntl = *tcount;
+            if (ntl <= MAX_CAND) {
+                for (int j = tid; j < ntl * 16; j += NTX) {
+                    const int idx = tlist[j >> 4] * 16 + (j & 15);
+                    float v = x[idx];
+                    if (bf16_round) v = (float)(bf16_t)v;
+                    const uint32_t kk = fkey(v / temperature);
+                    if (kk >= t0) {
+                        const int slot = atomicAdd(&S.n_cand, 1);
+                        if (slot < MAX_CAND) { S.ckey[slot] = kk; S.cidx[slot] = idx; }
                     }
                 }
+            } else if (tid == 0) {
+                S.n_cand = MAX_CAND + 1;
             }
             __syncthreads();
             if (S.n_cand <= MAX_CAND) fast = true;               // else pathological ties: the general path below
@@ -454,16 +468,16 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     // pass 0: stage, row max, NaN detection (16-byte loads, all of a thread's loads in flight at once)
     if (staged && (V & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
         const int V4 = V >> 2;
-        for (int i0 = tid; i0 < V4; i0 += NT * 8) {
+        for (int i0 = tid; i0 < V4; i0 += NTX * 8) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i4 = i0 + u * NT;
+                const int i4 = i0 + u * NTX;
                 if (i4 < V4) v[u] = reinterpret_cast<const float4 *>(x)[i4];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i4 = i0 + u * NT;
+                const int i4 = i0 + u * NTX;
                 if (i4 < V4) {
                     float4 z = v[u];
                     if (bf16_round) {
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
         __syncthreads();                                          // (any partition of the row works for the prefilter)
     } else {
-        for (int i = tid; i < V; i += NT) {
+        for (int i = tid; i < V; i += NTX) {
             const float z = load_z(i);
             if (staged) zs[i] = z;
             bad |= (z != z);
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     bad = block_sum_i(bad, S.redi);
     }
     if (!filter_only && (bad || m == INFINITY || m == -INFINITY)) { // exp(log_softmax) would hold NaN (utils.py:203)
-        for (int i = tid; i < V; i += NT) o[i] = __uint_as_float(0x7fc00000u);
+        for (int i = tid; i < V; i += NTX) o[i] = __uint_as_float(0x7fc00000u);
         if (tid == 0) {
             if (errp) *errp = 1;
             if (SAMPLE && samp_err) *samp_err = 1;
@@ -529,9 +543,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             if (tid == 0) S.n_cand = 0;
             __syncthreads();
             uint32_t t0 = S.redu[0];
-#pragma unroll
-            for (int i = 1; i < NT / 64; ++i) t0 = max(t0, S.redu[i]);
-            for (int i = tid; i < V; i += NT) {
+            for (int i = 1; i < NWX; ++i) t0 = max(t0, S.redu[i]);
+            for (int i = tid; i < V; i += NTX) {
                 const uint32_t kk = fkey(Z(i));
                 if (kk >= t0) {
                     const int slot = atomicAdd(&S.n_cand, 1);
@@ -556,7 +569,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t cand = prefix | (1u << bit);
                 int c = 0;
-                for (int i = tid; i < V; i += NT) c += (fkey(Z(i)) >= cand);
+                for (int i = tid; i < V; i += NTX) c += (fkey(Z(i)) >= cand);
                 c = block_sum_i(c, S.redi);
                 if (c >= k) prefix = cand;
             }
@@ -575,14 +588,14 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     float *ev = reinterpret_cast<float *>(S.ckey);
     auto fill_ev = [&](int n) {
         __syncthreads();
-        if (tid < n) ev[tid] = expf(funkey(S.skey[tid]) - m);
+        for (int c = tid; c < n; c += NTX) ev[c] = expf(funkey(S.skey[c]) - m);
         __syncthreads();
     };
     if (have_list) fill_ev(n_surv);
     if (top_p > 0.0f) {
         if (!have_list) {
             int c = 0;
-            for (int i = tid; i < V; i += NT) {
+            for (int i = tid; i < V; i += NTX) {
                 const uint32_t kk = fkey(Z(i));
                 c += (kk >= kth && kk > neg_inf_key);
             }
@@ -591,7 +604,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 __syncthreads();
                 if (tid == 0) S.n_cand = 0;
                 __syncthreads();
-                for (int i = tid; i < V; i += NT) {
+                for (int i = tid; i < V; i += NTX) {
                     const uint32_t kk = fkey(Z(i));
                     if (kk >= kth && kk > neg_inf_key) {
                         const int slot = atomicAdd(&S.n_cand, 1);
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             // i.e. float(mass strictly above v*) <= top_p, by bisection on the key; then how many of its tie
             // members fit.  Mass is accumulated in double like torch.cumsum does.
             float part = 0.f;
-            for (int i = tid; i < V; i += NT) {
+            for (int i = tid; i < V; i += NTX) {
                 const float z = Z(i);
                 if (fkey(z) >= kth) part += expf(z - m);
             }
@@ -639,7 +652,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             while (lo < hi) {
                 const uint32_t mid = lo + ((hi - lo) >> 1);
                 double g = 0.0;
-                for (int i = tid; i < V; i += NT) {
+                for (int i = tid; i < V; i += NTX) {
                     const float z = Z(i);
                     if (fkey(z) > mid) g += (double)(expf(z - m) / denom);
                 }
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 if (!((float)g > top_p)) hi = mid; else lo = mid + 1u;
             }
             uint32_t best = 0xffffffffu;                          // v* = smallest existing key >= lo
-            for (int i = tid; i < V; i += NT) {
+            for (int i = tid; i < V; i += NTX) {
                 const uint32_t kk = fkey(Z(i));
                 if (kk >= lo) best = min(best, kk);
             }
@@ -657,12 +670,12 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             if (lane == 0) S.redu[wv] = best;
             __syncthreads();
             best = S.redu[0];
-            for (int i2 = 1; i2 < NT / 64; ++i2) best = min(best, S.redu[i2]);
+            for (int i2 = 1; i2 < NWX; ++i2) best = min(best, S.redu[i2]);
             const uint32_t vstar = best;
             double g = 0.0;
             int e = 0;
             float pv = 0.f;
-            for (int i = tid; i < V; i += NT) {
+            for (int i = tid; i < V; i += NTX) {
                 const float z = Z(i);
                 const uint32_t kk = fkey(z);
                 if (kk > vstar) g += (double)(expf(z - m) / denom);
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 while (lo_i < hi_i) {
                     const int mid = lo_i + ((hi_i - lo_i) >> 1);
                     int c2 = 0;
-                    for (int i = tid; i < V; i += NT) c2 += (i <= mid && fkey(Z(i)) == vstar);
+                    for (int i = tid; i < V; i += NTX) c2 += (i <= mid && fkey(Z(i)) == vstar);
                     c2 = block_sum_i(c2, S.redi);
                     if (c2 >= mstar) hi_i = mid; else lo_i = mid + 1;
                 }
@@ -705,22 +718,23 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         if (fast) {
             // norm_cand_kernel zero-filled the row
         } else if ((V & 3) == 0 && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-            for (int i4 = tid; i4 < (V >> 2); i4 += NT) reinterpret_cast<float4 *>(o)[i4] = make_float4(fillv, fillv, fillv, fillv);
+            for (int i4 = tid; i4 < (V >> 2); i4 += NTX) reinterpret_cast<float4 *>(o)[i4] = make_float4(fillv, fillv, fillv, fillv);
         } else {
-            for (int i = tid; i < V; i += NT) o[i] = fillv;
+            for (int i = tid; i < V; i += NTX) o[i] = fillv;
         }
         __syncthreads();
         const float lse = S.lse;
-        if (tid < kept) o[S.sidx[tid]] = filter_only ? funkey(S.skey[tid]) : expf((funkey(S.skey[tid]) - m) - lse);
+        for (int c = tid; c < kept; c += NTX)
+            o[S.sidx[c]] = filter_only ? funkey(S.skey[c]) : expf((funkey(S.skey[c]) - m) - lse);
         STAMP(5);
         if (SAMPLE) {
             // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and never
             // win); first index wins ties; fix-up for a pick below 1e-9 (utils.py:228-230).  One lane per kept entry.
             ArgMax br = {0.f, 0x7fffffff};
-            if (tid < kept) {
-                const int id = S.sidx[tid];
-                const float p = expf((funkey(S.skey[tid]) - m) - lse);
-                if (p > 0.f) br = {p / (noise ? noise[id] : philox_exp(seed, draw, id)), id};
+            for (int c = tid; c < kept; c += NTX) {
+                const int id = S.sidx[c];
+                const float p = expf((funkey(S.skey[c]) - m) - lse);
+                if (p > 0.f) br = am_better(br, ArgMax{p / (noise ? noise[id] : philox_exp(seed, draw, id)), id});
             }
             ArgMax *sha = reinterpret_cast<ArgMax *>(S.ckey);
             br = block_argmax(br, sha);
@@ -736,7 +750,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
     } else {
         float part = 0.f;
-        for (int i = tid; i < V; i += NT) {
+        for (int i = tid; i < V; i += NTX) {
             const float z = Z(i);
             const uint32_t kk = fkey(z);
             if (kk > cut_key || (kk == cut_key && i <= cut_idx)) part += expf(z - m);
@@ -749,10 +763,10 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             if (filter_only) return keep ? z : -INFINITY;
             return keep ? expf((z - m) - lse) : 0.0f;
         };
-        for (int i = tid; i < V; i += NT) o[i] = P(i);
+        for (int i = tid; i < V; i += NTX) o[i] = P(i);
         if (SAMPLE) {
             ArgMax br = {0.f, 0x7fffffff}, bw = {0.f, 0x7fffffff};
-            for (int i = tid; i < V; i += NT) {
+            for (int i = tid; i < V; i += NTX) {
                 const float p = P(i);
                 if (!(p > 0.f)) continue;
                 const float r = p / (noise ? noise[i] : philox_exp(seed, draw, i));
@@ -1088,13 +1102,17 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
                            temperature, top_k, bf16_round_logits, probs_out, ld_out, ws, tab, use_tab);
         SD_LAUNCH_CHECK();
     }
+    // with tile maxima the work is a few dozen candidates: 4 waves (cheap barriers), no row staging
+    const int nthr = tile_max ? (getenv("SD_NORM_TILE_THREADS") ? atoi(getenv("SD_NORM_TILE_THREADS")) : 256) : NT;
+    const int staged_k = tile_max ? 0 : staged;
+    const size_t lds_k = tile_max ? base : lds;
     if (do_sample)
-        hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
-                           temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag, noise,
+        hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(nthr), lds_k, (hipStream_t)stream, logits, ld_in, V,
+                           temperature, top_k, top_p, bf16_round_logits, staged_k, probs_out, ld_out, err_flag, noise,
                            seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0, tile_max);
     else
-        hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(NT), lds, (hipStream_t)stream, logits, ld_in, V,
-                           temperature, top_k, top_p, bf16_round_logits, staged, probs_out, ld_out, err_flag,
+        hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(nthr), lds_k, (hipStream_t)stream, logits, ld_in, V,
+                           temperature, top_k, top_p, bf16_round_logits, staged_k, probs_out, ld_out, err_flag,
                            (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
                            (const CandRow *)ws, tab, use_tab, filter_only, tile_max);
     SD_LAUNCH_CHECK();

@@ -443,8 +443,11 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.bfloat16)
     ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 41))).to(torch.int32).cuda()[0]
     outs = {}
-    for flag in ("1", "0"):
-        os.environ["SD_SMALL_PATH"] = flag
+    modes = {"per_op": {"SD_SMALL_PATH": "0", "SD_FUSE_EMBED_QKV": "0"},      # one launch per op (the round-1 chain)
+             "default": {},                                                    # embedding + norm fused into QKV(0)
+             "1": {"SD_SMALL_PATH": "1"}}                                     # every norm fused into its consumer
+    for flag, env in modes.items():
+        os.environ.update(env)
         try:
             ses = m.new_session(64)
             ses.forward(ids[:30], 0)                              # prompt (many rows: the per-op chain either way)
@@ -454,9 +457,10 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
                 pos += q
             outs[flag] = (torch.cat(got), ses.kv[:, :, :, :pos].clone())
         finally:
-            os.environ.pop("SD_SMALL_PATH", None)
-    assert torch.equal(outs["1"][0], outs["0"][0])
-    assert torch.equal(outs["1"][1], outs["0"][1])
+            for k in env:
+                os.environ.pop(k, None)
+    outs["0"] = outs["per_op"]
+    assert torch.equal(outs["default"][0], outs["0"][0]) and torch.equal(outs["default"][1], outs["0"][1])
     om = oracle.RefCausalLM(cfg, sd)
     want = om(ids[None].long().cpu()).logits.float()[0, 30:41]
     got = outs["1"][0].cpu()
