@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SD_ABI_VERSION 1
+#define SD_ABI_VERSION 2
 
 typedef enum {
     SD_OK = 0,
@@ -34,6 +34,22 @@ typedef enum {
 } sd_status;
 
 typedef enum { SD_F32 = 0, SD_BF16 = 1 } sd_dtype;
+
+/* dtype_mode of the sampling entry points (the `bf16_round_logits` argument of the norm_* calls is this word too).
+ * The reference's Llama returns fp32 logits (modeling_llama.py:870: a 16-bit head's output cast with .float()), its OPT
+ * keeps them - and with them the whole norm_logits / sample / max_fn chain - in the weight dtype (modeling_opt.py:974).
+ *   SD_NORM_ROUND_*: the logits handed over are fp32 accumulators that still have to be rounded to the head's dtype;
+ *   SD_NORM_DT_*:    the row lives in that 16-bit dtype: every tensor the reference materialises on the way (logits /
+ *                    temperature, softmax, cumsum prefixes, the row sum and its log, log_softmax, exp, p - q, max_fn's
+ *                    sum and quotient, p / noise) is rounded to it, as torch's bf16 / fp16 CPU kernels do (fp32 math, one
+ *                    rounding per op).  Probability rows stay fp32 arrays; their values are then exactly representable.
+ * Ties: with 16-bit logits the top-p cut can fall inside a run of equal logits; the reference's order inside such a run
+ * is that of an unstable std::sort (torch.sort without stable=True, utils.py:170) and is not reproduced - this build
+ * keeps the lowest token ids. */
+#define SD_NORM_ROUND_BF16 1
+#define SD_NORM_ROUND_F16 2
+#define SD_NORM_DT_BF16 16
+#define SD_NORM_DT_F16 32
 typedef enum { SD_ARCH_LLAMA = 0, SD_ARCH_OPT = 1 } sd_arch;
 
 int sd_version(void);
@@ -92,7 +108,7 @@ int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temp
  * (seed, draw_index).  tok_out: device int32.  err_flag (device, may be NULL): 1 = invalid
  * distribution (negative / NaN / Inf), 2 = all-zero row; both are 'prob error' in the reference. */
 int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,
-              uint64_t draw_index, int *tok_out, int *err_flag, void *stream);
+              uint64_t draw_index, int *tok_out, int *err_flag, int dtype_mode, void *stream);
 
 /* The device RNG of the throughput mode made observable, so that a test can replay the exact variates into the CPU
  * oracle (the reference draws from torch's generator, utils.py:221 / speculative_sampling.py:1978; this build's
@@ -105,7 +121,7 @@ int sd_philox_uniform(uint64_t philox_seed, uint64_t draw_index, int n, float *o
 /* max_fn (utils.py:236-245) materialised: out = max(p-q,0) / (sum(max(p-q,0)) + 1e-6).  q may be
  * NULL (then max_fn(p)).  Only the drop-in sampling.utils.max_fn uses this; the decode loop uses
  * the fused sd_resample below and never writes the residual row. */
-int sd_max_fn(const float *p, const float *q, int V, float *out, void *stream);
+int sd_max_fn(const float *p, const float *q, int V, float *out, int dtype_mode, void *stream);
 
 /* Result block written by the accept / resample kernels (device or pinned-host memory). */
 typedef struct {
@@ -135,7 +151,7 @@ int sd_accept_scan(const float *p_hist, const float *q_hist, long ld, const int3
  * token at seq[n+1] and stores the new sequence length n+2 into *seq_len (device int, may be NULL). */
 int sd_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L,
                 int gamma, const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
-                sd_accept_result *res, int32_t *seq_len, void *stream);
+                sd_accept_result *res, int32_t *seq_len, int dtype_mode, void *stream);
 
 /* sd_accept_scan + sd_resample for up to 16 independent streams in two launches (stream-batched decode).
  * Per item: its probability arenas, token buffer, prefix length L, the gamma uniforms r (or NULL: Philox
@@ -151,7 +167,7 @@ typedef struct {
     const int *err_flags;
     int32_t n_err;
 } sd_accept_item;
-int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, void *stream);
+int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, int dtype_mode, void *stream);
 
 /* Width-w acceptance of multi_speculative_sampling(strategy="iid") (speculative_sampling.py:1592-1640, SURVEY.md 8(f)
  * rank 2): replica w drafted seq_w[L .. L+gamma); replicas are scanned in order, replica w accepts its i-th token iff
@@ -178,7 +194,7 @@ int sd_accept_multi(const sd_multi_item *items, int width, long ld, int L, int g
  * sample raises, the token is drawn from p_n itself, not from max_fn(p_n).  Everything else as sd_resample. */
 int sd_multi_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
                       const float *exp_noise, uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res,
-                      void *stream);
+                      int dtype_mode, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder model + KV arena           reference sampling/models/modeling_{llama,opt}.py,

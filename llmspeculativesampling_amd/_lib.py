@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libspecdec.so")
 
 SD_OK, SD_ERR_INVALID, SD_ERR_NORM_LOGITS, SD_ERR_PROB, SD_ERR_HIP, SD_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 SD_F32, SD_BF16 = 0, 1
+SD_NORM_ROUND_BF16, SD_NORM_ROUND_F16, SD_NORM_DT_BF16, SD_NORM_DT_F16 = 1, 2, 16, 32
 N_PROFILE_CLASSES = 8
 PROFILE_CLASS_NAMES = ["gemm", "attention", "norm_residual", "qkv_rope_append", "activation", "embed",
                        "logits", "other"]
@@ -79,15 +80,15 @@ SYMBOLS = [
     ("sd_norm_workspace_bytes", C.c_size_t, [_I]),
     ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_norm_batch", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, C.POINTER(SdNormRow), _I, _VP, _VP]),
-    ("sd_accept_batch", _I, [C.POINTER(SdAcceptItem), _I, _L, _I, _I, _VP]),
+    ("sd_accept_batch", _I, [C.POINTER(SdAcceptItem), _I, _L, _I, _I, _I, _VP]),
     ("sd_accept_multi", _I, [C.POINTER(SdMultiItem), _I, _L, _I, _I, _VP, _U64, _U64, _VP, _VP]),
-    ("sd_multi_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _VP, _U64, _U64, _VP, _VP]),
-    ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_multi_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _VP, _U64, _U64, _VP, _I, _VP]),
+    ("sd_sample", _I, [_VP, _I, _VP, _U64, _U64, _VP, _VP, _I, _VP]),
     ("sd_philox_exp", _I, [_U64, _U64, _I, _VP, _VP]),
     ("sd_philox_uniform", _I, [_U64, _U64, _I, _VP, _VP]),
-    ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _VP]),
+    ("sd_max_fn", _I, [_VP, _VP, _I, _VP, _I, _VP]),
     ("sd_accept_scan", _I, [_VP, _VP, _L, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP]),
-    ("sd_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP, _VP]),
+    ("sd_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _VP, _VP, _I, _VP]),
     ("sd_model_create", _I, [C.POINTER(SdModelConfig), C.POINTER(SdModelWeights), C.POINTER(_VP)]),
     ("sd_model_destroy", _I, [_VP]),
     ("sd_model_max_rows", _I, [_VP]),

@@ -1051,7 +1051,13 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, in
 // here synchronises; the caller waits on the stream once per iteration.
 int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
                             uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res, const int *err_flags,
-                            int n_err, hipStream_t st);
+                            int n_err, int dtype_mode, hipStream_t st);
+
+// SD_NORM_DT_* of a model's probability rows: OPT keeps logits and probabilities in the weight dtype
+// (modeling_opt.py:974), Llama casts its logits to fp32 (modeling_llama.py:870)
+static int storage_mode(const sd_model *m) {
+    return (m->cfg.arch == SD_ARCH_OPT && m->cfg.dtype == SD_BF16) ? SD_NORM_DT_BF16 : 0;
+}
 
 struct sd_spec {
     sd_session *draft, *target;
@@ -1171,7 +1177,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         if (rc != SD_OK) return rc;
         draft_len = upto;
         if ((rc = sd_norm_rows_with_tiles(sp->draft->last_logits, 1, V, sp->draft->last_logits_ld, sp->temperature, sp->top_k,
-                                          sp->top_p, sp->draft->last_logits_round, q_row, sp->ld, sp->err + i, seed_draft,
+                                          sp->top_p, sp->draft->last_logits_round | storage_mode(sp->draft->m), q_row, sp->ld, sp->err + i, seed_draft,
                                           draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws,
                                           sp->draft->last_tile_max, stream)) != SD_OK)
             return rc;
@@ -1190,7 +1196,8 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         sp->target->head_zero_rows = nullptr;
         if (rc != SD_OK) return rc;
         if ((rc = sd_norm_rows_with_tiles(sp->target->last_logits, rows, V, sp->target->last_logits_ld, sp->temperature,
-                                          sp->top_k, sp->top_p, sp->target->last_logits_round, p_rows, sp->ld, sp->err + 2 * g,
+                                          sp->top_k, sp->top_p, sp->target->last_logits_round | storage_mode(sp->target->m), p_rows,
+                                          sp->ld, sp->err + 2 * g,
                                           0, 0, nullptr, nullptr, sp->norm_ws, sp->target->last_tile_max, stream)) != SD_OK)
             return rc;
     }
@@ -1198,8 +1205,10 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     // ---- accept scan + residual / bonus sample
     if ((rc = sd_accept_scan(sp->p_hist, sp->q_hist, sp->ld, sp->seq, L, g, r_const, seed_accept, draw_scan0, sp->res_dev, stream)) != SD_OK)
         return rc;
+    // p - q, max_fn and the draw are in the rows' dtype when both models keep 16-bit rows
+    const int res_mode = storage_mode(sp->target->m) == storage_mode(sp->draft->m) ? storage_mode(sp->target->m) : 0;
     if ((rc = sd_resample_with_errors(sp->p_hist, sp->q_hist, sp->ld, V, sp->seq, g, seed_accept, draw_resample, sp->res_dev,
-                                      sp->err, 3 * g + 1, st)) != SD_OK)
+                                      sp->err, 3 * g + 1, res_mode, st)) != SD_OK)
         return rc;
     SD_HIP_CHECK(hipMemcpyAsync(res_host, sp->res_dev, sizeof(sd_accept_result), hipMemcpyDeviceToHost, st));
     if (tok_host)       // optional second copy; the result block already carries the drafted tokens and the next one

@@ -115,6 +115,20 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t draw) {
     return u01_half(o.x);
 }
 
+// ---- storage-dtype arithmetic (SD_NORM_* in specdec.h).  The reference keeps OPT's logits and the whole norm_logits /
+// sample / max_fn chain in the weight dtype (modeling_opt.py:974, utils.py:182-245); torch's CPU kernels for bf16 / fp16
+// compute each op in fp32 and round its result to the tensor dtype, so "dtype-faithful" = fp32 math with a rounding
+// to the storage type wherever torch materialises a tensor.  dt: 0 fp32 (no rounding), 1 bf16, 2 fp16.
+__device__ __forceinline__ float rnd_dt(float x, int dt) {
+    return dt == 1 ? (float)(bf16_t)x : (dt == 2 ? (float)(_Float16)x : x);
+}
+// value of a logit as the model's head leaves it: mode bits 0-1 = rounding of the fp32 accumulator (1 bf16, 2 fp16)
+__device__ __forceinline__ float head_round(float x, int mode) { return rnd_dt(x, mode & 3); }
+// z = logits / temperature (utils.py:197), rounded when the row lives in a 16-bit dtype (mode bits 4-5)
+__device__ __forceinline__ float scaled_logit(float x, float temperature, int mode) {
+    return rnd_dt(head_round(x, mode) / temperature, (mode >> 4) & 3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // norm_probs
 // ---------------------------------------------------------------------------------------------
@@ -227,8 +241,8 @@ __global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict_
         const int i4 = lo + tid + u * 256;
         if (i4 < hi) {
             float4 v = z[u];
-            if (bf16_round) { v.x = (float)(bf16_t)v.x; v.y = (float)(bf16_t)v.y; v.z = (float)(bf16_t)v.z; v.w = (float)(bf16_t)v.w; }
-            v.x = v.x / temperature; v.y = v.y / temperature; v.z = v.z / temperature; v.w = v.w / temperature;
+            v.x = scaled_logit(v.x, temperature, bf16_round); v.y = scaled_logit(v.y, temperature, bf16_round);
+            v.z = scaled_logit(v.z, temperature, bf16_round); v.w = scaled_logit(v.w, temperature, bf16_round);
             z[u] = v;
             bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
             mt = fmaxf(fmaxf(mt, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     float *zs = reinterpret_cast<float *>(smem + ((sizeof(NormShared) + 15) & ~size_t(15)));
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int NTX = blockDim.x, NWX = NTX >> 6;         // 1024 threads, or 256 when the head left tile maxima
+    const int dt = (bf16_round >> 4) & 3;               // storage dtype of the row's arithmetic (0 fp32, 1 bf16, 2 fp16)
     const float *x = logits + (size_t)row * ld_in;
     float *o = use_tab ? tab.out[blockIdx.x] : out + (size_t)row * ld_out;
     int *errp = use_tab ? tab.err[blockIdx.x] : (err ? err + row : nullptr);
@@ -313,9 +328,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
     const uint32_t neg_inf_key = 0x007fffffu;                     // fkey(-inf)
 
     auto load_z = [&](int i) -> float {
-        float v = x[i];
-        if (bf16_round) v = (float)(bf16_t)v;
-        return v / temperature;                                   // utils.py:197
+        return scaled_logit(x[i], temperature, bf16_round);      // utils.py:197
     };
     STAMP(0);
     // fast entry: norm_cand_kernel already cut the row down to a candidate list (and zero-filled the output row)
@@ -405,8 +418,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             if (t < NTL) {
                 float v = tm[t];
                 bad |= (v != v);
-                if (bf16_round) v = (float)(bf16_t)v;
-                v = v / temperature;                              // temperature > 0: monotone, max commutes with it
+                v = scaled_logit(v, temperature, bf16_round);    // temperature > 0: monotone, max commutes with it
                 zt[u] = v;
                 mtl = fmaxf(mtl, v);
             }
@@ -444,9 +456,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             if (ntl <= MAX_CAND) {
                 for (int j = tid; j < ntl * 16; j += NTX) {
                     const int idx = tlist[j >> 4] * 16 + (j & 15);
-                    float v = x[idx];
-                    if (bf16_round) v = (float)(bf16_t)v;
-                    const uint32_t kk = fkey(v / temperature);
+                    const uint32_t kk = fkey(scaled_logit(x[idx], temperature, bf16_round));
                     if (kk >= t0) {
                         const int slot = atomicAdd(&S.n_cand, 1);
                         if (slot < MAX_CAND) { S.ckey[slot] = kk; S.cidx[slot] = idx; }
@@ -480,10 +490,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 const int i4 = i0 + u * NTX;
                 if (i4 < V4) {
                     float4 z = v[u];
-                    if (bf16_round) {
-                        z.x = (float)(bf16_t)z.x; z.y = (float)(bf16_t)z.y; z.z = (float)(bf16_t)z.z; z.w = (float)(bf16_t)z.w;
-                    }
-                    z.x = z.x / temperature; z.y = z.y / temperature; z.z = z.z / temperature; z.w = z.w / temperature;
+                    z.x = scaled_logit(z.x, temperature, bf16_round); z.y = scaled_logit(z.y, temperature, bf16_round);
+                    z.z = scaled_logit(z.z, temperature, bf16_round); z.w = scaled_logit(z.w, temperature, bf16_round);
                     reinterpret_cast<float4 *>(zs)[i4] = z;
                     bad |= (z.x != z.x) | (z.y != z.y) | (z.z != z.z) | (z.w != z.w);
                     mt = fmaxf(fmaxf(mt, fmaxf(z.x, z.y)), fmaxf(z.z, z.w));
@@ -626,13 +634,25 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 while (nf > 1 && S.skey[nf - 1] <= neg_inf_key) --nf;
                 float denom = 0.f;                                // softmax denominator over the survivors
                 for (int i = 0; i < nf; ++i) denom += ev[i];
-                // torch.cumsum accumulates float32 inputs in double and rounds each prefix to float32
-                double cum = 0.0;
+                // torch.cumsum accumulates float32 inputs in double and rounds each prefix to float32; bf16 / fp16 inputs
+                // (softmax output rounded to the dtype) accumulate in float, each prefix is rounded to the dtype and
+                // compared with top_p rounded to it (utils.py:171-173 on a 16-bit tensor)
                 int kp = 0;
-                for (int i = 0; i < nf; ++i) {
-                    if (i > 0 && (float)cum > top_p) break;       // shifted filter: the crossing token stays
-                    cum += (double)(ev[i] / denom);
-                    kp = i + 1;
+                if (dt == 0) {
+                    double cum = 0.0;
+                    for (int i = 0; i < nf; ++i) {
+                        if (i > 0 && (float)cum > top_p) break;   // shifted filter: the crossing token stays
+                        cum += (double)(ev[i] / denom);
+                        kp = i + 1;
+                    }
+                } else {
+                    float cum = 0.f;
+                    const float tp = rnd_dt(top_p, dt);
+                    for (int i = 0; i < nf; ++i) {
+                        if (i > 0 && rnd_dt(cum, dt) > tp) break;
+                        cum += rnd_dt(ev[i] / denom, dt);
+                        kp = i + 1;
+                    }
                 }
                 S.kept = kp;
             }
@@ -654,10 +674,10 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 double g = 0.0;
                 for (int i = tid; i < V; i += NTX) {
                     const float z = Z(i);
-                    if (fkey(z) > mid) g += (double)(expf(z - m) / denom);
+                    if (fkey(z) > mid) g += (double)rnd_dt(expf(z - m) / denom, dt);
                 }
                 g = block_sum_d(g, S.redd);
-                if (!((float)g > top_p)) hi = mid; else lo = mid + 1u;
+                if (!(rnd_dt((float)g, dt) > rnd_dt(top_p, dt))) hi = mid; else lo = mid + 1u;
             }
             uint32_t best = 0xffffffffu;                          // v* = smallest existing key >= lo
             for (int i = tid; i < V; i += NTX) {
@@ -678,8 +698,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             for (int i = tid; i < V; i += NTX) {
                 const float z = Z(i);
                 const uint32_t kk = fkey(z);
-                if (kk > vstar) g += (double)(expf(z - m) / denom);
-                if (kk == vstar) { e += 1; pv = expf(z - m) / denom; }
+                if (kk > vstar) g += (double)rnd_dt(expf(z - m) / denom, dt);
+                if (kk == vstar) { e += 1; pv = rnd_dt(expf(z - m) / denom, dt); }
             }
             g = block_sum_d(g, S.redd);
             e = block_sum_i(e, S.redi);
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             int mstar = 1;                                        // first tie member is kept by construction
             {
                 double cum = g + (double)pv;
-                while (mstar < e && !((float)cum > top_p)) { cum += (double)pv; ++mstar; }
+                while (mstar < e && !(rnd_dt((float)cum, dt) > rnd_dt(top_p, dt))) { cum += (double)pv; ++mstar; }
             }
             cut_key = vstar;
             cut_idx = 0x7fffffff;
@@ -712,7 +732,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         if (tid == 0) {
             float sum = 0.f;
             for (int i = 0; i < kept; ++i) sum += ev[i];
-            S.lse = logf(sum);
+            // 16-bit rows: torch's log_softmax keeps the row sum and its log in the tensor dtype
+            S.lse = dt ? rnd_dt(logf(rnd_dt(sum, dt)), dt) : logf(sum);
         }
         const float fillv = filter_only ? -INFINITY : 0.f;
         if (fast) {
@@ -724,8 +745,12 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         }
         __syncthreads();
         const float lse = S.lse;
+        auto PL = [&](uint32_t key) -> float {                    // exp(log_softmax): both results live in the row dtype
+            const float ls = (funkey(key) - m) - lse;
+            return dt ? rnd_dt(expf(rnd_dt(ls, dt)), dt) : expf(ls);
+        };
         for (int c = tid; c < kept; c += NTX)
-            o[S.sidx[c]] = filter_only ? funkey(S.skey[c]) : expf((funkey(S.skey[c]) - m) - lse);
+            o[S.sidx[c]] = filter_only ? funkey(S.skey[c]) : PL(S.skey[c]);
         STAMP(5);
         if (SAMPLE) {
             // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and never
@@ -733,8 +758,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             ArgMax br = {0.f, 0x7fffffff};
             for (int c = tid; c < kept; c += NTX) {
                 const int id = S.sidx[c];
-                const float p = expf((funkey(S.skey[c]) - m) - lse);
-                if (p > 0.f) br = am_better(br, ArgMax{p / (noise ? noise[id] : philox_exp(seed, draw, id)), id});
+                const float p = PL(S.skey[c]);
+                if (p > 0.f) br = am_better(br, ArgMax{rnd_dt(p / (noise ? noise[id] : philox_exp(seed, draw, id)), dt), id});
             }
             ArgMax *sha = reinterpret_cast<ArgMax *>(S.ckey);
             br = block_argmax(br, sha);
@@ -742,7 +767,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                 int tok = br.i;
                 float ptok = 0.f;
                 for (int i = 0; i < kept; ++i)
-                    if (S.sidx[i] == tok) ptok = expf((funkey(S.skey[i]) - m) - lse);
+                    if (S.sidx[i] == tok) ptok = PL(S.skey[i]);
                 if (tok == 0x7fffffff || ptok < 1e-9f) tok = S.sidx[0];   // argmax(probs): list head (lowest index among ties)
                 *tok_out = tok;
                 if (samp_err) *samp_err = 0;
@@ -755,13 +780,15 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             const uint32_t kk = fkey(z);
             if (kk > cut_key || (kk == cut_key && i <= cut_idx)) part += expf(z - m);
         }
-        const float lse = logf(block_sum(part, S.redf));
+        const float rowsum = block_sum(part, S.redf);
+        const float lse = dt ? rnd_dt(logf(rnd_dt(rowsum, dt)), dt) : logf(rowsum);
         auto P = [&](int i) -> float {
             const float z = Z(i);
             const uint32_t kk = fkey(z);
             const bool keep = kk > cut_key || (kk == cut_key && i <= cut_idx);
             if (filter_only) return keep ? z : -INFINITY;
-            return keep ? expf((z - m) - lse) : 0.0f;
+            if (!keep) return 0.0f;
+            return dt ? rnd_dt(expf(rnd_dt((z - m) - lse, dt)), dt) : expf((z - m) - lse);
         };
         for (int i = tid; i < V; i += NTX) o[i] = P(i);
         if (SAMPLE) {
@@ -769,7 +796,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
             for (int i = tid; i < V; i += NTX) {
                 const float p = P(i);
                 if (!(p > 0.f)) continue;
-                const float r = p / (noise ? noise[i] : philox_exp(seed, draw, i));
+                const float r = rnd_dt(p / (noise ? noise[i] : philox_exp(seed, draw, i)), dt);
                 if (br.i == 0x7fffffff || r > br.v) br = {r, i};
                 if (bw.i == 0x7fffffff || p > bw.v) bw = {p, i};
             }
@@ -800,7 +827,7 @@ struct SampleShared {
 
 // W(i) -> weight, E(i) -> Exp(1) noise.  Returns the token; *status: 0 ok, 1 invalid, 2 all-zero.
 template <typename WF, typename EF>
-__device__ __forceinline__ int sample_core(int V, WF W, EF E, SampleShared &S, int *status) {
+__device__ __forceinline__ int sample_core(int V, WF W, EF E, SampleShared &S, int *status, int dt = 0) {
     const int tid = threadIdx.x;
     ArgMax best_r = {0.f, 0x7fffffff}, best_w = {0.f, 0x7fffffff};
     int bad = 0, pos = 0;
@@ -808,7 +835,7 @@ __device__ __forceinline__ int sample_core(int V, WF W, EF E, SampleShared &S, i
         const float w = W(i);
         bad |= !(w >= 0.0f) || (w == INFINITY);                   // negative, NaN or Inf: multinomial's validity check
         pos |= (w > 0.0f);
-        const float r = w > 0.0f ? w / E(i) : 0.0f;               // IEEE division, as at::div; 0/e = 0 needs no variate
+        const float r = w > 0.0f ? rnd_dt(w / E(i), dt) : 0.0f;   // IEEE division, as at::div (result in the row dtype); 0/e = 0
         if (best_r.i == 0x7fffffff || r > best_r.v) best_r = {r, i};
         if (best_w.i == 0x7fffffff || w > best_w.v) best_w = {w, i};
     }
@@ -826,30 +853,35 @@ __device__ __forceinline__ int sample_core(int V, WF W, EF E, SampleShared &S, i
 
 __global__ __launch_bounds__(NT) void sample_kernel(const float *__restrict__ probs, int V,
                                                    const float *__restrict__ noise, uint64_t seed, uint64_t draw,
-                                                   int *__restrict__ tok_out, int *__restrict__ err) {
+                                                   int *__restrict__ tok_out, int *__restrict__ err, int dt) {
     __shared__ SampleShared S;
     int status;
     const int tok = sample_core(
         V, [&](int i) { return probs[i]; },
-        [&](int i) { return noise ? noise[i] : philox_exp(seed, draw, i); }, S, &status);
+        [&](int i) { return noise ? noise[i] : philox_exp(seed, draw, i); }, S, &status, dt);
     if (threadIdx.x == 0) {
         if (status == 0) *tok_out = tok;
         if (err) *err = status;
     }
 }
 
+// max_fn's denominator (utils.py:245): sum + 1e-6; on a 16-bit row the sum is a tensor of that dtype and so is the result
+__device__ __forceinline__ float max_fn_denom(float sum, int dt) {
+    return dt ? rnd_dt(rnd_dt(sum, dt) + 1e-6f, dt) : sum + 1e-6f;
+}
+
 __global__ __launch_bounds__(NT) void max_fn_kernel(const float *__restrict__ p, const float *__restrict__ q, int V,
-                                                   float *__restrict__ out) {
+                                                   float *__restrict__ out, int dt) {
     __shared__ float red[16];
     float part = 0.f;
     for (int i = threadIdx.x; i < V; i += NT) {
-        const float d = q ? p[i] - q[i] : p[i];
+        const float d = q ? rnd_dt(p[i] - q[i], dt) : p[i];
         part += d > 0.f ? d : 0.f;
     }
-    const float denom = block_sum(part, red) + 1e-6f;
+    const float denom = max_fn_denom(block_sum(part, red), dt);
     for (int i = threadIdx.x; i < V; i += NT) {
-        const float d = q ? p[i] - q[i] : p[i];
-        out[i] = (d > 0.f ? d : 0.f) / denom;
+        const float d = q ? rnd_dt(p[i] - q[i], dt) : p[i];
+        out[i] = rnd_dt((d > 0.f ? d : 0.f) / denom, dt);
     }
 }
 
@@ -917,7 +949,7 @@ __device__ __forceinline__ void resample_body(const float *__restrict__ p_hist, 
                                               long ld, int V, int32_t *__restrict__ seq, int gamma,
                                               const float *__restrict__ noise, uint64_t seed, uint64_t draw,
                                               sd_accept_result *__restrict__ res, int32_t *__restrict__ seq_len,
-                                              const int *__restrict__ err_flags, int n_err) {
+                                              const int *__restrict__ err_flags, int n_err, int dt = 0) {
     __shared__ SampleShared S;
     __shared__ float red[16];
     const int n = res->n;
@@ -929,25 +961,26 @@ __device__ __forceinline__ void resample_body(const float *__restrict__ p_hist, 
     if (rejected) {
         float part = 0.f;
         for (int i = threadIdx.x; i < V; i += NT) {
-            const float d = p[i] - q[i];
+            const float d = rnd_dt(p[i] - q[i], dt);
             part += d > 0.f ? d : 0.f;
         }
-        const float denom = block_sum(part, red) + 1e-6f;         // max_fn, utils.py:236-245
+        const float denom = max_fn_denom(block_sum(part, red), dt);   // max_fn, utils.py:236-245
         tok = sample_core(
-            V, [&](int i) { const float d = p[i] - q[i]; return (d > 0.f ? d : 0.f) / denom; }, E, S, &status);
+            V, [&](int i) { const float d = rnd_dt(p[i] - q[i], dt); return rnd_dt((d > 0.f ? d : 0.f) / denom, dt); }, E, S,
+            &status, dt);
         if (status != 0) {                                        // residual sample raised -> sample(max_fn(p_n)) (:2009-2010)
             flags |= 1;
             part = 0.f;
             for (int i = threadIdx.x; i < V; i += NT) part += p[i] > 0.f ? p[i] : 0.f;
-            const float denom2 = block_sum(part, red) + 1e-6f;
+            const float denom2 = max_fn_denom(block_sum(part, red), dt);
             if (PLAIN_FALLBACK)                                   // multi_speculative_sampling: sample(p_n) (:1666-1668)
-                tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status);
+                tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status, dt);
             else
                 tok = sample_core(
-                    V, [&](int i) { const float d = p[i]; return (d > 0.f ? d : 0.f) / denom2; }, E, S, &status);
+                    V, [&](int i) { const float d = p[i]; return rnd_dt((d > 0.f ? d : 0.f) / denom2, dt); }, E, S, &status, dt);
         }
     } else {
-        tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status);   // bonus token from p_last (:2019)
+        tok = sample_core(V, [&](int i) { return p[i]; }, E, S, &status, dt);   // bonus token from p_last (:2019)
     }
     if (threadIdx.x == 0) {
         if (status != 0) flags |= 2;
@@ -966,17 +999,17 @@ __global__ __launch_bounds__(NT) void resample_kernel(const float *__restrict__ 
                                                      const float *__restrict__ noise, uint64_t seed, uint64_t draw,
                                                      sd_accept_result *__restrict__ res,
                                                      int32_t *__restrict__ seq_len,
-                                                     const int *__restrict__ err_flags, int n_err) {
-    resample_body(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, seq_len, err_flags, n_err);
+                                                     const int *__restrict__ err_flags, int n_err, int dt) {
+    resample_body(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, seq_len, err_flags, n_err, dt);
 }
 
 __global__ __launch_bounds__(NT) void multi_resample_kernel(const float *__restrict__ p_hist,
                                                            const float *__restrict__ q_hist, long ld, int V,
                                                            int32_t *__restrict__ seq, int gamma,
                                                            const float *__restrict__ noise, uint64_t seed,
-                                                           uint64_t draw, sd_accept_result *__restrict__ res) {
+                                                           uint64_t draw, sd_accept_result *__restrict__ res, int dt) {
     resample_body<true>(p_hist, q_hist, ld, V, seq, gamma, noise, seed, draw, res, (int32_t *)nullptr,
-                        (const int *)nullptr, 0);
+                        (const int *)nullptr, 0, dt);
 }
 
 // Width-w acceptance (multi_speculative_sampling): gathers in parallel, the data-dependent scan on one thread.
@@ -1035,10 +1068,10 @@ __global__ __launch_bounds__(256) void accept_multi_kernel(MultiTab t, int width
     }
 }
 
-__global__ __launch_bounds__(NT) void resample_batch_kernel(AcceptTab t, long ld, int V, int gamma) {
+__global__ __launch_bounds__(NT) void resample_batch_kernel(AcceptTab t, long ld, int V, int gamma, int dt) {
     const int b = blockIdx.x;
     resample_body(t.p_hist[b], t.q_hist[b], ld, V, t.seq[b], gamma, t.noise[b], t.seed[b], t.draw_res[b], t.res[b],
-                  (int32_t *)nullptr, t.err_flags[b], t.n_err[b]);
+                  (int32_t *)nullptr, t.err_flags[b], t.n_err[b], dt);
 }
 
 // The device RNG made observable (tests replay it into the CPU oracle): out[i] = the Exp(1) variate element i of
@@ -1187,18 +1220,20 @@ extern "C" int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in,
     return SD_OK;
 }
 
+static inline int mode_dt(int dtype_mode) { return (dtype_mode >> 4) & 3; }
+
 extern "C" int sd_sample(const float *probs, int V, const float *exp_noise, uint64_t philox_seed,
-                         uint64_t draw_index, int *tok_out, int *err_flag, void *stream) {
+                         uint64_t draw_index, int *tok_out, int *err_flag, int dtype_mode, void *stream) {
     SD_REQUIRE(probs && tok_out && V > 0, "sd_sample: bad arguments");
     hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, probs, V, exp_noise, philox_seed,
-                       draw_index, tok_out, err_flag);
+                       draw_index, tok_out, err_flag, mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
 
-extern "C" int sd_max_fn(const float *p, const float *q, int V, float *out, void *stream) {
+extern "C" int sd_max_fn(const float *p, const float *q, int V, float *out, int dtype_mode, void *stream) {
     SD_REQUIRE(p && out && V > 0, "sd_max_fn: bad arguments");
-    hipLaunchKernelGGL(max_fn_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, q, V, out);
+    hipLaunchKernelGGL(max_fn_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p, q, V, out, mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -1216,11 +1251,11 @@ extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld,
 
 extern "C" int sd_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
                            const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
-                           sd_accept_result *res, int32_t *seq_len, void *stream) {
+                           sd_accept_result *res, int32_t *seq_len, int dtype_mode, void *stream) {
     SD_REQUIRE(p_hist && q_hist && seq && res && V > 0, "sd_resample: bad arguments");
     (void)L;
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p_hist, q_hist, ld, V, seq, gamma,
-                       exp_noise, philox_seed, draw_index, res, seq_len, (const int *)nullptr, 0);
+                       exp_noise, philox_seed, draw_index, res, seq_len, (const int *)nullptr, 0, mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -1228,9 +1263,10 @@ extern "C" int sd_resample(const float *p_hist, const float *q_hist, long ld, in
 // internal: the same with the iteration's error words folded into res->flags bit3 (used by sd_spec_iteration)
 int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
                             uint64_t philox_seed, uint64_t draw_index, sd_accept_result *res, const int *err_flags,
-                            int n_err, hipStream_t st) {
+                            int n_err, int dtype_mode, hipStream_t st) {
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, gamma,
-                       (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err);
+                       (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err,
+                       mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -1252,16 +1288,17 @@ extern "C" int sd_accept_multi(const sd_multi_item *items, int width, long ld, i
 
 extern "C" int sd_multi_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int gamma,
                                  const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
-                                 sd_accept_result *res, void *stream) {
+                                 sd_accept_result *res, int dtype_mode, void *stream) {
     SD_REQUIRE(p_hist && q_hist && seq && res && V > 0, "sd_multi_resample: bad arguments");
     hipLaunchKernelGGL(multi_resample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p_hist, q_hist, ld, V, seq,
-                       gamma, exp_noise, philox_seed, draw_index, res);
+                       gamma, exp_noise, philox_seed, draw_index, res, mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
 
 // Accept scan + residual / bonus sample for up to 16 independent streams in two launches (stream-batched decode).
-extern "C" int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, void *stream) {
+extern "C" int sd_accept_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, int dtype_mode,
+                               void *stream) {
     SD_REQUIRE(items && n_items >= 1 && n_items <= SD_ACCEPT_BATCH, "sd_accept_batch: 1..%d items", SD_ACCEPT_BATCH);
     SD_REQUIRE(gamma >= 1 && gamma <= 16 && V > 0, "sd_accept_batch: bad gamma / V");
     AcceptTab t = {};
@@ -1274,7 +1311,8 @@ extern "C" int sd_accept_batch(const sd_accept_item *items, int n_items, long ld
     }
     hipLaunchKernelGGL(accept_scan_batch_kernel, dim3(n_items), dim3(64), 0, (hipStream_t)stream, t, ld, gamma);
     SD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(resample_batch_kernel, dim3(n_items), dim3(NT), 0, (hipStream_t)stream, t, ld, V, gamma);
+    hipLaunchKernelGGL(resample_batch_kernel, dim3(n_items), dim3(NT), 0, (hipStream_t)stream, t, ld, V, gamma,
+                       mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }

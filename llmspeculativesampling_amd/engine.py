@@ -74,6 +74,10 @@ class SpecDecModel:
         self._arrays = []
         self.weight_bytes = 0                        # bytes the forward streams (embedding tables excluded)
         self.fused = dtype == torch.bfloat16 and cfg.intermediate_size % 8 == 0 and cfg.head_dim % 4 == 0
+        # dtype of the probability rows the reference would keep for this model (kvcache_model.py:167-168 on the model's
+        # logits): OPT's logits stay in the weight dtype (modeling_opt.py:974), Llama's are cast to fp32 (:870)
+        self.probs_dtype = dtype if cfg.arch == "opt" else torch.float32
+        self.norm_mode = {torch.bfloat16: _lib.SD_NORM_DT_BF16, torch.float16: _lib.SD_NORM_DT_F16}.get(self.probs_dtype, 0)
         self._build(get_tensor)
 
     # -- weight staging ---------------------------------------------------------------------

@@ -43,21 +43,24 @@ class HostTorchNoise:
         self.device = device
         self.gen = generator            # None = torch's global default generator, like the reference
 
-    def exponential(self, V: int) -> torch.Tensor:
-        e = torch.empty(V, dtype=torch.float32).exponential_(1, generator=self.gen)
-        return e.to(self.device, non_blocking=False)
+    # ``dtype``: the dtype of the probability row being sampled.  torch.multinomial draws its noise as
+    # empty_like(probs).exponential_(1): a 16-bit row consumes the generator differently from an fp32 one and its
+    # variates are rounded to that dtype (they are uploaded as fp32 holding those values).
+    def exponential(self, V: int, dtype=torch.float32) -> torch.Tensor:
+        e = torch.empty(V, dtype=dtype).exponential_(1, generator=self.gen)
+        return e.float().to(self.device, non_blocking=False)
 
-    def skip_exponential(self, V: int) -> None:
-        torch.empty(V, dtype=torch.float32).exponential_(1, generator=self.gen)
+    def skip_exponential(self, V: int, dtype=torch.float32) -> None:
+        torch.empty(V, dtype=dtype).exponential_(1, generator=self.gen)
 
-    def exponential_rows(self, rows: int, V: int) -> torch.Tensor:
+    def exponential_rows(self, rows: int, V: int, dtype=torch.float32) -> torch.Tensor:
         """One draw of shape (rows, V): what torch.multinomial consumes for a (rows, V) input
         (multi_speculative_sampling's width-w samples, kvcache_model.py:283 with multi > 1)."""
-        e = torch.empty((rows, V), dtype=torch.float32).exponential_(1, generator=self.gen)
-        return e.to(self.device, non_blocking=False)
+        e = torch.empty((rows, V), dtype=dtype).exponential_(1, generator=self.gen)
+        return e.float().to(self.device, non_blocking=False)
 
-    def skip_exponential_rows(self, rows: int, V: int) -> None:
-        torch.empty((rows, V), dtype=torch.float32).exponential_(1, generator=self.gen)
+    def skip_exponential_rows(self, rows: int, V: int, dtype=torch.float32) -> None:
+        torch.empty((rows, V), dtype=dtype).exponential_(1, generator=self.gen)
 
     def uniforms(self, gamma: int, random_seed) -> Tuple[torch.Tensor, object]:
         """gamma uniforms as the reference would draw them if nothing were rejected, plus a token to
@@ -113,20 +116,20 @@ class ReplayNoise:
         self.pos += 1
         return v
 
-    def exponential(self, V: int) -> torch.Tensor:
-        e = torch.as_tensor(self._take("exp"), dtype=torch.float32).reshape(-1)
+    def exponential(self, V: int, dtype=None) -> torch.Tensor:
+        e = torch.as_tensor(self._take("exp")).to(torch.float32).reshape(-1)
         assert e.numel() == V
         return e.to(self.device)
 
-    def skip_exponential(self, V: int) -> None:
+    def skip_exponential(self, V: int, dtype=None) -> None:
         self._take("exp")
 
-    def exponential_rows(self, rows: int, V: int) -> torch.Tensor:
-        e = torch.as_tensor(self._take("exp"), dtype=torch.float32)
+    def exponential_rows(self, rows: int, V: int, dtype=None) -> torch.Tensor:
+        e = torch.as_tensor(self._take("exp")).to(torch.float32)
         assert e.numel() == rows * V, (tuple(e.shape), rows, V)
         return e.reshape(rows, V).contiguous().to(self.device)
 
-    def skip_exponential_rows(self, rows: int, V: int) -> None:
+    def skip_exponential_rows(self, rows: int, V: int, dtype=None) -> None:
         e = torch.as_tensor(self._take("exp"))
         assert e.numel() == rows * V
 

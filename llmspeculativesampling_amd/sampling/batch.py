@@ -121,7 +121,7 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
                 rows[j].sample_err = s.err_ptr + 4 * (gamma + i)
                 s.draft_len = L + i
             check(lib.sd_norm_batch(logits.data_ptr(), n, V, logits.stride(0), float(temperature), int(top_k or 0),
-                                    float(top_p or 0.0), 0, rows, 1, norm_ws.data_ptr(), cu), "sd_norm_batch")
+                                    float(top_p or 0.0), draft_m.norm_mode, rows, 1, norm_ws.data_ptr(), cu), "sd_norm_batch")
         # ---- verify: the uncached rows of every stream, max_verify streams per pass over the target weights
         if _timing is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
@@ -142,7 +142,7 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
                     rows[k].err = s.err_ptr + 4 * (2 * gamma + min(r, gamma))
                     k += 1
             check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(temperature), int(top_k or 0),
-                                    float(top_p or 0.0), 0, rows, 0, norm_ws.data_ptr(), cu), "sd_norm_batch")
+                                    float(top_p or 0.0), target_m.norm_mode, rows, 0, norm_ws.data_ptr(), cu), "sd_norm_batch")
         if _timing is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
@@ -170,7 +170,8 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
             it.res = res_base + s.idx * res_sz
             it.err_flags = s.err_ptr
             it.n_err = n_err
-        check(lib.sd_accept_batch(items, n, act[0].draft._probs.stride(0), V, gamma, cu), "sd_accept_batch")
+        res_mode = target_m.norm_mode if target_m.norm_mode == draft_m.norm_mode else 0
+        check(lib.sd_accept_batch(items, n, act[0].draft._probs.stride(0), V, gamma, res_mode, cu), "sd_accept_batch")
         res_host.copy_(res_dev, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         raw = res_host.numpy()

@@ -76,8 +76,8 @@ class KVCacheModel:
             return None
         if self._width > 1:
             return torch.stack([self._probs[: self._hist_len]] +
-                               [r[1][: self._hist_len] for r in self._replicas[: self._width - 1]])
-        return self._probs[: self._hist_len].unsqueeze(0)
+                               [r[1][: self._hist_len] for r in self._replicas[: self._width - 1]]).to(self._model.probs_dtype)
+        return self._probs[: self._hist_len].unsqueeze(0).to(self._model.probs_dtype)
 
     @property
     def cache_len(self) -> int:
@@ -106,7 +106,7 @@ class KVCacheModel:
             logits = ses.forward(seq32[ses.cache_len:end], blk)
             t1 = process_time_ns()
             check(lib.sd_norm_probs(logits.data_ptr(), blk, V, logits.stride(0), float(self._temperature),
-                                    int(self._top_k or 0), float(self._top_p or 0.0), 0,
+                                    int(self._top_k or 0), float(self._top_p or 0.0), self._model.norm_mode,
                                     self._probs[end - blk].data_ptr(), self._probs.stride(0),
                                     self._err[end - blk].data_ptr(), self._norm_ws.data_ptr(), st), "sd_norm_probs")
             self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
@@ -138,10 +138,11 @@ class KVCacheModel:
         if noise.on_device:
             e_ptr, seed, draw = None, noise.seed, noise.next_draws(1)
         else:
-            e = noise.exponential(V)
+            e = noise.exponential(V, self._model.probs_dtype)
             e_ptr, seed, draw = e.data_ptr(), 0, 0
         check(lib.sd_norm_sample(logits.data_ptr(), V, float(self._temperature), int(self._top_k or 0),
-                                 float(self._top_p or 0.0), 0, self._probs[row].data_ptr(), self._err[row].data_ptr(),
+                                 float(self._top_p or 0.0), self._model.norm_mode, self._probs[row].data_ptr(),
+                                 self._err[row].data_ptr(),
                                  e_ptr, seed, draw, seq32[upto].data_ptr(), samp_err.data_ptr(), self._norm_ws.data_ptr(),
                                  _stream()),
               "sd_norm_sample")
@@ -174,7 +175,7 @@ class KVCacheModel:
         rows = n_new if (self._full_history or cached > 0) else 1
         self.forward_rows(self._tok32, S, rows)
         self.check_errors(S - rows, S)
-        return self._probs[S - 1].unsqueeze(0)
+        return self._probs[S - 1].unsqueeze(0).to(self._model.probs_dtype)
 
     @torch.no_grad()
     def generate(self, input: torch.Tensor, gamma: int, decoder_input_ids=None, attention_mask=None,
@@ -253,7 +254,7 @@ class KVCacheModel:
             if on_dev:
                 e_base, seed, draw0 = 0, noise.seed, noise.next_draws(W)
             else:
-                e = noise.exponential_rows(W, V)                  # ONE (W, V) draw, like torch.multinomial on (W, V)
+                e = noise.exponential_rows(W, V, m.probs_dtype)   # ONE (W, V) draw, like torch.multinomial on (W, V)
                 e_base, seed, draw0 = e.data_ptr(), 0, 0
             grp = max(1, per_pass // n_new)
             for a in range(0, W, grp):
@@ -275,16 +276,17 @@ class KVCacheModel:
                         k += 1
                 if n_out == 1:
                     check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(self._temperature),
-                                            int(self._top_k or 0), float(self._top_p or 0.0), 0, rows, 1,
+                                            int(self._top_k or 0), float(self._top_p or 0.0), m.norm_mode, rows, 1,
                                             self._norm_ws.data_ptr(), st), "sd_norm_batch")
                 else:
                     # several history rows per replica: normalise all of them, then sample each replica's last row
                     check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(self._temperature),
-                                            int(self._top_k or 0), float(self._top_p or 0.0), 0, rows, 0,
+                                            int(self._top_k or 0), float(self._top_p or 0.0), m.norm_mode, rows, 0,
                                             self._norm_ws.data_ptr(), st), "sd_norm_batch")
                     for w in ws:
                         check(lib.sd_sample(probs[w][upto - 1].data_ptr(), V, (e_base + w * V * 4) if e_base else None,
-                                            seed, draw0 + w, toks[w][upto:].data_ptr(), serr[w:].data_ptr(), st), "sd_sample")
+                                            seed, draw0 + w, toks[w][upto:].data_ptr(), serr[w:].data_ptr(), m.norm_mode, st),
+                              "sd_sample")
             if self._hist_len == 0:
                 self._hist_lo = upto - n_out
             self._hist_len = upto

@@ -101,6 +101,7 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
     for w in range(W):
         items[w].p_hist, items[w].q_hist, items[w].seq = p_ptr[w], q_ptr[w], seq_ptr[w]
     Tk, Kk, Pk = float(temperature), int(top_k or 0), float(top_p or 0.0)
+    res_mode = target_m.norm_mode if target_m.norm_mode == draft_m.norm_mode else 0
 
     acc_len, acc_rate = [], []
     approx_time = target_time = other_time = 0
@@ -122,7 +123,7 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
                 if on_dev:
                     e_base, seed, draw0 = 0, noise.seed, noise.next_draws(W)
                 else:
-                    e = noise.exponential_rows(W, V)                   # ONE (width, V) draw, like torch.multinomial
+                    e = noise.exponential_rows(W, V, draft_m.probs_dtype)   # ONE (width, V) draw, like torch.multinomial
                     e_base, seed, draw0 = e.data_ptr(), 0, 0
                 rows = (SdNormRow * W)()
                 for w in range(W):
@@ -133,7 +134,7 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
                     rows[w].draw_index = draw0 + w
                     rows[w].tok_out = seq_ptr[w] + 4 * (L + i)
                     rows[w].sample_err = err_ptr + 4 * (w * n_err + gamma + i)
-                check(lib.sd_norm_batch(logits.data_ptr(), W, V, logits.stride(0), Tk, Kk, Pk, 0, rows, 1,
+                check(lib.sd_norm_batch(logits.data_ptr(), W, V, logits.stride(0), Tk, Kk, Pk, draft_m.norm_mode, rows, 1,
                                         norm_ws.data_ptr(), cu), "sd_norm_batch")
                 draft_len = L + i
             approx_calls += 1
@@ -156,13 +157,13 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
                         rows[k].probs_out = p_ptr[w] + pos * ld_bytes
                         rows[k].err = err_ptr + 4 * (w * n_err + 2 * gamma + min(r_, gamma))
                         k += 1
-                check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), Tk, Kk, Pk, 0, rows, 0,
+                check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), Tk, Kk, Pk, target_m.norm_mode, rows, 0,
                                         norm_ws.data_ptr(), cu), "sd_norm_batch")
             # the target's own sample, drawn and thrown away by the reference (kvcache_model.py:283)
             if on_dev:
                 noise.next_draws(W)
             else:
-                noise.skip_exponential_rows(W, V)
+                noise.skip_exponential_rows(W, V, target_m.probs_dtype)
             target_calls += 1
             target_time += process_time_ns() - tt
             tt = process_time_ns()
@@ -208,10 +209,10 @@ def multi_speculative_sampling(prefix: torch.Tensor, approx_model, target_model,
             if on_dev:
                 e_ptr, seed, draw = None, noise.seed, noise.next_draws(1)
             else:
-                e1 = noise.exponential(V)
+                e1 = noise.exponential(V, target_m.probs_dtype if res_mode else torch.float32)
                 e_ptr, seed, draw = e1.data_ptr(), 0, 0
             check(lib.sd_multi_resample(p_ptr[choice], q_ptr[choice], ld, V, seq_ptr[choice], gamma, e_ptr, seed, draw,
-                                        res_dev.data_ptr(), cu), "sd_multi_resample")
+                                        res_dev.data_ptr(), res_mode, cu), "sd_multi_resample")
             res_host.copy_(res_dev, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             res = SdMultiResult.from_buffer_copy(res_host.numpy().tobytes())

@@ -77,6 +77,9 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
     q_hist, p_hist = draft._probs, target._probs
     ld = q_hist.stride(0)
     st = _stream()
+    # p - q, max_fn and the residual draw run in the rows' dtype when both models keep 16-bit rows (OPT)
+    res_mode = target_m.norm_mode if target_m.norm_mode == draft_m.norm_mode else 0
+    res_dtype = target_m.probs_dtype if res_mode else torch.float32
 
     if getattr(noise, "on_device", False) and not verbose:
         return _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos_token_id, T, gamma,
@@ -106,7 +109,7 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
             if noise.on_device:
                 noise.next_draws(1)
             else:
-                noise.skip_exponential(V)
+                noise.skip_exponential(V, target_m.probs_dtype)
             target_calls += 1
             target_time += process_time_ns() - tick
             tick = process_time_ns()
@@ -126,7 +129,7 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
                                              None, noise.seed, noise.next_draws(gamma), res_dev.data_ptr(), st),
                           "sd_accept_scan")
                 check(lib.sd_resample(p_hist.data_ptr(), q_hist.data_ptr(), ld, V, seq32.data_ptr(), L, gamma, None,
-                                      noise.seed, noise.next_draws(1), res_dev.data_ptr(), None, st), "sd_resample")
+                                      noise.seed, noise.next_draws(1), res_dev.data_ptr(), None, res_mode, st), "sd_resample")
             else:
                 r, token = noise.uniforms(gamma, random_seed)
                 check(lib.sd_accept_scan(p_hist.data_ptr(), q_hist.data_ptr(), ld, seq32.data_ptr(), L, gamma,
@@ -137,9 +140,9 @@ def speculative_sampling(prefix: torch.Tensor, approx_model, target_model, eos_t
                     torch.cuda.current_stream().synchronize()
                     l_now = SdAcceptResult.from_buffer_copy(res_host.numpy().tobytes()).n_accepted
                     noise.realign(token, min(l_now + 1, gamma))
-                e = noise.exponential(V)
+                e = noise.exponential(V, res_dtype)
                 check(lib.sd_resample(p_hist.data_ptr(), q_hist.data_ptr(), ld, V, seq32.data_ptr(), L, gamma,
-                                      e.data_ptr(), 0, 0, res_dev.data_ptr(), None, st), "sd_resample")
+                                      e.data_ptr(), 0, 0, res_dev.data_ptr(), None, res_mode, st), "sd_resample")
             res_host.copy_(res_dev, non_blocking=True)
             tok_host.copy_(seq32[L:L + gamma + 2], non_blocking=True)
             torch.cuda.current_stream().synchronize()

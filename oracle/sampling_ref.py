@@ -9,6 +9,14 @@ import torch.nn.functional as F
 
 from .noise import TorchGlobalNoise
 
+# Tie order inside runs of equal logits after the descending sort of top_k_top_p_filter.  The reference calls
+# torch.sort(descending=True) without stable=True (utils.py:170): on CPU that is an unstable std::sort whose order among
+# equal keys is unspecified (observed: neither ascending nor descending ids).  It only matters when the top-p cut falls
+# inside such a run, which fp32 logits practically never produce and bf16 / fp16 logits often do.  False = exactly the
+# reference's call; True = ties in ascending token id, the rule the HIP kernels implement - the fixtures generator uses
+# it to mark the low-precision cases whose result depends on the unspecified order.
+STABLE_TIES = False
+
 
 def top_k_top_p_filter(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0) -> torch.Tensor:
     """reference utils.py:152-179.  Works on a copy (the reference mutates the
@@ -19,8 +27,7 @@ def top_k_top_p_filter(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0)
         kth = torch.topk(z, min(top_k, z.size(-1)))[0][:, -1:]
         z = z.masked_fill(z < kth, float("-inf"))
     if top_p is not None and top_p > 0.0:
-        # torch.sort on CPU is stable: equal logits keep ascending-index order
-        srt, order = torch.sort(z, descending=True)
+        srt, order = torch.sort(z, descending=True, stable=True) if STABLE_TIES else torch.sort(z, descending=True)
         cum = torch.cumsum(F.softmax(srt, dim=-1), dim=-1)
         over = cum > top_p
         # shift right by one: the first token that crosses top_p is kept (utils.py:174-176)

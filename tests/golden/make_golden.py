@@ -347,6 +347,107 @@ def g4_accept():
     print("G4:", len(cases), "cases; acc_len samples:", [c["acc_len"][:6] for c in cases[:6]])
 
 
+def g8_lowprec():
+    """bf16 / fp16 rows through the reference's norm_logits / sample / max_fn and its whole accept / resample loop
+    (position-table models whose logits are 16-bit, as OPT's are: modeling_opt.py:974).  `tie_sensitive` marks the cases
+    whose result depends on the order torch's unstable descending sort gives equal logits (oracle.sampling_ref.STABLE_TIES):
+    there the HIP kernels (ties in ascending token id) legitimately differ from the recorded run."""
+    import oracle.sampling_ref as SR
+    cases, blobs = dict(norm=[], sample=[], max_fn=[], trace=[]), {}
+
+    def stable(fn):
+        SR.STABLE_TIES = True
+        try:
+            return fn()
+        finally:
+            SR.STABLE_TIES = False
+    cid = 0
+    for V in (32000, 50272, 4096):
+        for (T, k, p) in [(1.0, 20, 0.9), (0.7, 50, 0.95), (1.3, 5, 0.0), (1.0, 1, 0.0), (0.8, 64, 0.99), (1.0, 0, 0.0)]:
+            for dtype in (torch.bfloat16, torch.float16):
+                if (k == 0) and V != 4096:
+                    continue                                  # the plain-softmax row only once (dense)
+                seed = 1200 + cid
+                x = logits_row(seed, V, dtype=dtype)
+                probs = ref_utils.norm_logits(x.clone(), T, k, p)
+                assert probs.dtype == dtype and torch.equal(oracle.norm_logits(x.clone(), T, k, p), probs)
+                st = stable(lambda: oracle.norm_logits(x.clone(), T, k, p))
+                pf = probs.float().numpy()[0]
+                nz = np.nonzero(pf)[0]
+                key = f"n{cid}"
+                blobs[key + "_idx"], blobs[key + "_val"] = nz.astype(np.int32), pf[nz]
+                cases["norm"].append(dict(id=key, seed=seed, V=V, scale=4.0, T=T, k=k, p=p, dtype=str(dtype).split(".")[1],
+                                          tie_sensitive=not torch.equal(st, probs)))
+                cid += 1
+    # sample on 16-bit rows: the noise is a 16-bit tensor too (empty_like(probs).exponential_)
+    for i, (V, dtype) in enumerate([(32000, torch.bfloat16), (32000, torch.float16), (50272, torch.bfloat16), (4096, torch.float16)]):
+        for rep in range(3):
+            seed = 1500 + 10 * i + rep
+            probs = ref_utils.norm_logits(logits_row(seed, V, dtype=dtype), 1.0, 20, 0.9)
+            _real_seed(9500 + 10 * i + rep)
+            capture_on()
+            tok = ref_utils.sample(probs)
+            ev = capture_off()
+            assert len(ev) == 1 and ev[0][1].dtype == dtype
+            key = f"s{i}_{rep}"
+            blobs[key + "_noise"] = ev[0][1].float().numpy()[0]
+            nz = np.nonzero(probs.float().numpy()[0])[0]
+            blobs[key + "_pidx"], blobs[key + "_pval"] = nz.astype(np.int32), probs.float().numpy()[0][nz]
+            cases["sample"].append(dict(id=key, V=V, dtype=str(dtype).split(".")[1], token=int(tok)))
+    # max_fn(p - q) on 16-bit rows
+    for i, (V, dtype) in enumerate([(32000, torch.bfloat16), (32000, torch.float16), (4096, torch.bfloat16)]):
+        pr = ref_utils.norm_logits(logits_row(1700 + i, V, dtype=dtype), 1.0, 20, 0.9)
+        qr = ref_utils.norm_logits((logits_row(1700 + i, V) + 0.7 * logits_row(1800 + i, V, 1.0)).to(dtype), 1.0, 20, 0.9)
+        res = ref_utils.max_fn(pr - qr)
+        assert res.dtype == dtype and torch.equal(oracle.max_fn(pr - qr), res)
+        for nm, t in (("p", pr), ("q", qr), ("r", res)):
+            a = t.float().numpy()[0]
+            nz = np.nonzero(a)[0]
+            blobs[f"m{i}_{nm}idx"], blobs[f"m{i}_{nm}val"] = nz.astype(np.int32), a[nz]
+        cases["max_fn"].append(dict(id=f"m{i}", V=V, dtype=str(dtype).split(".")[1]))
+    # the whole loop over 16-bit position tables
+    tid = 0
+    V, L, S = 512, 6, 64
+    for dtype in (torch.bfloat16, torch.float16):
+        for gamma, sigma, seeded in [(4, 0.3, None), (4, 1.0, None), (4, 0.3, 42), (2, 0.5, None), (8, 0.2, None), (4, 0.0, None)]:
+            rng = np.random.default_rng([4800, tid])
+            z = rng.standard_normal((S, V), dtype=np.float32) * 2.0
+            eps = rng.standard_normal((S, V), dtype=np.float32) * 2.0
+            qt, pt = torch.from_numpy(z).to(dtype), torch.from_numpy(z + np.float32(sigma) * eps).to(dtype)
+            qm, pm = TableModel(qt), TableModel(pt)
+            prompt = torch.from_numpy(rng.integers(3, V, size=(1, L)))
+            _real_seed(7800 + tid)
+            capture_on()
+            out, d = ref_ss.speculative_sampling(prompt, qm, pm, eos_token_id=2, pad_token_id=None, max_len=24, gamma=gamma,
+                                                 temperature=1, top_k=10, top_p=0.9, random_seed=seeded, details=True)
+            ev = capture_off()
+            assert all(e[1].dtype == dtype for e in ev if e[0] == "exp")
+            ro = oracle.speculative_sampling(prompt, qm, pm, 2, None, 24, gamma=gamma, temperature=1, top_k=10, top_p=0.9,
+                                             random_seed=seeded, details=True, noise=oracle.RecordedNoise(ev))
+            assert torch.equal(ro[0], out) and ro[1]["acc_len"] == d["acc_len"], "oracle != reference (G8)"
+            try:
+                rs = stable(lambda: oracle.speculative_sampling(prompt, qm, pm, 2, None, 24, gamma=gamma, temperature=1,
+                                                                top_k=10, top_p=0.9, random_seed=seeded, details=True,
+                                                                noise=oracle.RecordedNoise(ev)))
+                tie = not (torch.equal(rs[0], out) and rs[1]["acc_len"] == d["acc_len"])
+            except Exception:
+                tie = True
+            ev32 = [(k2, (v.float() if k2 == "exp" else v)) for k2, v in ev]
+            for k2, v in pack_events(ev32).items():
+                blobs[f"t{tid}_{k2}"] = v
+            blobs[f"t{tid}_out"] = out.numpy()[0].astype(np.int32)
+            blobs[f"t{tid}_prompt"] = prompt.numpy()[0].astype(np.int32)
+            cases["trace"].append(dict(id=f"t{tid}", V=V, L=L, S=S, gamma=gamma, sigma=sigma, random_seed=seeded,
+                                       table_seed=[4800, tid], top_k=10, top_p=0.9, max_len=24, dtype=str(dtype).split(".")[1],
+                                       acc_len=d["acc_len"], acc_rate=float(d["acc_rate"]),
+                                       target_call_times=d["target_call_times"], tie_sensitive=tie))
+            tid += 1
+    np.savez_compressed(os.path.join(HERE, "g8_lowprec.npz"), **blobs)
+    json.dump(cases, open(os.path.join(HERE, "g8_lowprec.json"), "w"), indent=0)
+    print("G8:", {k: len(v) for k, v in cases.items()}, "tie-sensitive norm rows:",
+          sum(c["tie_sensitive"] for c in cases["norm"]), "traces:", sum(c["tie_sensitive"] for c in cases["trace"]))
+
+
 def g5_traces():
     """End-to-end token traces of the reference's own model classes on tiny configs."""
     cases, blobs = [], {}
@@ -592,7 +693,7 @@ def misc():
 
 
 if __name__ == "__main__":
-    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi)
+    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi, g8=g8_lowprec)
     for name in (sys.argv[1:] or list(todo)):             # e.g. `make_golden.py g7` regenerates one fixture set
         todo[name]()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))

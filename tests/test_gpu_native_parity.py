@@ -465,3 +465,44 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     want = om(ids[None].long().cpu()).logits.float()[0, 30:41]
     got = outs["1"][0].cpu()
     assert float((got - want[: got.shape[0]]).abs().max()) <= 0.04 * float(want.abs().max())
+
+
+# --------------------------------------------------------------------------- config 3: OPT in bf16 end to end
+def test_opt_bf16_pair_end_to_end_vs_oracle(hip):
+    """BASELINE config 3's family (OPT draft -> OPT target, bf16): OPT keeps its logits in the weight dtype, so the
+    probability histories, the accept ratios, max_fn(p - q) and every draw run in bf16 (SD_NORM_DT_BF16).  Same outer
+    seed into the oracle's bf16 CPU run and the HIP run (live host generator, which also consumes bf16 noise rows): the
+    two bf16 forwards round in a different order, so an occasional token may flip; the bar is a long identical prefix
+    and matching acceptance statistics.  Also: native device-RNG loop == Python-orchestrated loop bit for bit."""
+    dcfg = ModelConfig(arch="opt", vocab_size=8192, hidden_size=128, ffn_dim=512, num_hidden_layers=2, num_attention_heads=2,
+                       max_position_embeddings=512, do_layer_norm_before=True, word_embed_proj_dim=128)
+    tcfg = ModelConfig(arch="opt", vocab_size=8192, hidden_size=256, ffn_dim=1024, num_hidden_layers=3, num_attention_heads=4,
+                       max_position_embeddings=512, do_layer_norm_before=True, word_embed_proj_dim=256)
+    dsd = make_state_dict(dcfg, 41, dtype=torch.bfloat16)
+    tsd = make_state_dict(tcfg, 42, dtype=torch.bfloat16)
+    # correlate the pair: the target's embedding / head start from the draft's (padded), so accepts really occur
+    with torch.no_grad():
+        tsd["model.decoder.embed_tokens.weight"][:, :128] = dsd["model.decoder.embed_tokens.weight"]
+        tsd["lm_head.weight"] = tsd["model.decoder.embed_tokens.weight"]
+    prompt = torch.from_numpy(np.random.default_rng(3).integers(3, 8192, size=(1, 20)))
+    torch.manual_seed(21)
+    want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd), 2, None, 32,
+                                           gamma=4, top_k=20, top_p=0.9, details=True)
+    dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.bfloat16)
+    tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.bfloat16)
+    assert dm.norm_mode == hip.L.SD_NORM_DT_BF16 and dm.probs_dtype == torch.bfloat16
+    torch.manual_seed(21)
+    got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, 2, None, 32, gamma=4, top_k=20, top_p=0.9, details=True)
+    w, g = want[0].tolist(), got[0].cpu().tolist()
+    common = next((i for i, (a, b) in enumerate(zip(w, g)) if a != b), min(len(w), len(g)))
+    print("OPT bf16: identical prefix", common - 20, "generated tokens; acc_len oracle", wd["acc_len"], "hip", gd["acc_len"])
+    assert common >= 20 + 6, (common, w, g)
+    assert abs(float(np.mean(gd["acc_len"])) - float(np.mean(wd["acc_len"]))) <= 1.0
+    kv = hip.S.KVCacheModel(tm, 1.0, 20, 0.9)
+    q = kv._forward_with_kvcache(prompt.cuda())
+    assert q.dtype == torch.bfloat16 and kv._prob_history.dtype == torch.bfloat16      # the reference's history dtype
+    a, da = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 32, gamma=4, top_k=20, top_p=0.9, details=True,
+                                       rng=hip.noise.DeviceNoise(9))
+    b, db = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 32, gamma=4, top_k=20, top_p=0.9, details=True,
+                                       rng=hip.noise.DeviceNoise(9), verbose=True)
+    assert torch.equal(a, b) and da["acc_len"] == db["acc_len"]

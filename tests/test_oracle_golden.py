@@ -229,3 +229,65 @@ def test_forward_logits_golden(case):
         np.testing.assert_allclose(o.logits.float().numpy()[0], want, atol=tol, rtol=0)
         past, pos = o.past_key_values, pos + q
     assert list(past[0][0].shape) == case["kv_shape"]
+
+
+# --------------------------------------------------------------------------- G8: bf16 / fp16 rows (OPT keeps 16-bit logits)
+G8_META, G8 = load("g8_lowprec")
+
+
+def _sparse(V, blobs, key_idx, key_val, dtype=torch.float32):
+    return torch.from_numpy(dense_from_sparse(V, blobs[key_idx], blobs[key_val]))[None].to(dtype)
+
+
+@pytest.mark.parametrize("case", G8_META["norm"], ids=[c["id"] for c in G8_META["norm"]])
+def test_lowprec_norm_logits_golden(case):
+    dt = DT[case["dtype"]]
+    x = logits_row(case["seed"], case["V"], case["scale"], dtype=dt)
+    got = oracle.norm_logits(x, case["T"], case["k"], case["p"])
+    assert got.dtype == dt
+    want = dense_from_sparse(case["V"], G8[case["id"] + "_idx"], G8[case["id"] + "_val"])
+    np.testing.assert_array_equal(got.float().numpy()[0], want)
+
+
+@pytest.mark.parametrize("case", G8_META["sample"], ids=[c["id"] for c in G8_META["sample"]])
+def test_lowprec_sample_golden(case):
+    dt = DT[case["dtype"]]
+    probs = _sparse(case["V"], G8, case["id"] + "_pidx", case["id"] + "_pval", dt)
+    noise = torch.from_numpy(G8[case["id"] + "_noise"].copy())[None]
+    assert int(oracle.sample(probs, oracle.RecordedNoise([("exp", noise)]))) == case["token"]
+
+
+@pytest.mark.parametrize("case", G8_META["max_fn"], ids=[c["id"] for c in G8_META["max_fn"]])
+def test_lowprec_max_fn_golden(case):
+    dt = DT[case["dtype"]]
+    p = _sparse(case["V"], G8, case["id"] + "_pidx", case["id"] + "_pval", dt)
+    q = _sparse(case["V"], G8, case["id"] + "_qidx", case["id"] + "_qval", dt)
+    want = _sparse(case["V"], G8, case["id"] + "_ridx", case["id"] + "_rval")
+    got = oracle.max_fn(p - q)
+    assert got.dtype == dt and torch.equal(got.float(), want)
+
+
+def lowprec_table_models(case):
+    dt = DT[case["dtype"]]
+    rng = np.random.default_rng(case["table_seed"])
+    z = rng.standard_normal((case["S"], case["V"]), dtype=np.float32) * 2.0
+    eps = rng.standard_normal((case["S"], case["V"]), dtype=np.float32) * 2.0
+    q = TableModel(torch.from_numpy(z).to(dt))
+    p = TableModel(torch.from_numpy(z + np.float32(case["sigma"]) * eps).to(dt))
+    prompt = torch.from_numpy(rng.integers(3, case["V"], size=(1, case["L"])))
+    return q, p, prompt
+
+
+@pytest.mark.parametrize("case", G8_META["trace"], ids=[c["id"] for c in G8_META["trace"]])
+def test_lowprec_accept_block_golden(case):
+    """The reference's whole loop over models with 16-bit logits: norm_logits, sample, the accept ratios, max_fn(p - q)
+    and the residual draw all run in bf16 / fp16 there."""
+    qm, pm, prompt = lowprec_table_models(case)
+    np.testing.assert_array_equal(prompt.numpy()[0], G8[case["id"] + "_prompt"])
+    noise = oracle.RecordedNoise(events(G8, case["id"]))
+    out, d = oracle.speculative_sampling(prompt, qm, pm, 2, None, case["max_len"], gamma=case["gamma"],
+                                         top_k=case["top_k"], top_p=case["top_p"], random_seed=case["random_seed"],
+                                         details=True, noise=noise)
+    np.testing.assert_array_equal(out.numpy()[0], G8[case["id"] + "_out"])
+    assert d["acc_len"] == case["acc_len"] and d["target_call_times"] == case["target_call_times"]
+    assert noise.exhausted()
