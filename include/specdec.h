@@ -33,7 +33,7 @@ typedef enum {
     SD_ERR_CAPACITY = -5      /* sequence / row count beyond what the session was sized for        */
 } sd_status;
 
-typedef enum { SD_F32 = 0, SD_BF16 = 1 } sd_dtype;
+typedef enum { SD_F32 = 0, SD_BF16 = 1, SD_F16 = 2 } sd_dtype;   /* fp16: what the reference harness loads (evaluation.py:185) */
 
 /* dtype_mode of the sampling entry points (the `bf16_round_logits` argument of the norm_* calls is this word too).
  * The reference's Llama returns fp32 logits (modeling_llama.py:870: a 16-bit head's output cast with .float()), its OPT

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspecdec.so")
 
 SD_OK, SD_ERR_INVALID, SD_ERR_NORM_LOGITS, SD_ERR_PROB, SD_ERR_HIP, SD_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
-SD_F32, SD_BF16 = 0, 1
+SD_F32, SD_BF16, SD_F16 = 0, 1, 2
 SD_NORM_ROUND_BF16, SD_NORM_ROUND_F16, SD_NORM_DT_BF16, SD_NORM_DT_F16 = 1, 2, 16, 32
 N_PROFILE_CLASSES = 8
 PROFILE_CLASS_NAMES = ["gemm", "attention", "norm_residual", "qkv_rope_append", "activation", "embed",

@@ -8,6 +8,7 @@
 #include "../../include/specdec.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 
 void sd_set_error(const char *fmt, ...);
 
@@ -30,13 +31,15 @@ void sd_set_error(const char *fmt, ...);
 
 #define SD_LAUNCH_CHECK() SD_HIP_CHECK(hipGetLastError())
 
-// ---- activation dtype helpers: T is float or bf16_t.  rnd<T>(x) rounds an fp32 value to the
+// ---- activation dtype helpers: T is float, bf16_t or f16_t.  rnd<T>(x) rounds an fp32 value to the
 // storage type and back, which is how every per-op result of a bf16 reference model is rounded.
 __device__ __forceinline__ float to_f(float x) { return x; }
 __device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f(f16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f(float x);
 template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float x) { return (f16_t)x; }
 template <typename T> __device__ __forceinline__ float rnd(float x) { return to_f(from_f<T>(x)); }
 
 // ---- wave / block reductions (wave = 64 lanes)

@@ -64,7 +64,10 @@ struct sd_session {
     hipStream_t prof_stream;
 };
 
-static inline size_t esize(int dtype) { return dtype == SD_BF16 ? 2 : 4; }
+static inline size_t esize(int dtype) { return dtype == SD_F32 ? 4 : 2; }
+static inline bool is16(int dtype) { return dtype != SD_F32; }
+// rounding code of a 16-bit head's fp32 accumulators (SD_NORM_ROUND_*)
+static inline int round_code(int dtype) { return dtype == SD_BF16 ? SD_NORM_ROUND_BF16 : (dtype == SD_F16 ? SD_NORM_ROUND_F16 : 0); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static void copy_ptrs(std::vector<const void *> &dst, const void *const *src, int n) {
@@ -76,15 +79,15 @@ static void copy_ptrs(std::vector<const void *> &dst, const void *const *src, in
 extern "C" int sd_model_create(const sd_model_config *cfg, const sd_model_weights *w, sd_model **out) {
     SD_REQUIRE(cfg && w && out, "sd_model_create: null argument");
     SD_REQUIRE(cfg->arch == SD_ARCH_LLAMA || cfg->arch == SD_ARCH_OPT, "sd_model_create: unknown arch %d", cfg->arch);
-    SD_REQUIRE(cfg->dtype == SD_F32 || cfg->dtype == SD_BF16, "sd_model_create: unknown dtype %d", cfg->dtype);
+    SD_REQUIRE(cfg->dtype == SD_F32 || cfg->dtype == SD_BF16 || cfg->dtype == SD_F16, "sd_model_create: unknown dtype %d", cfg->dtype);
     SD_REQUIRE(cfg->head_dim == 16 || cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128,
                "sd_model_create: head_dim %d not in {16,32,64,128}", cfg->head_dim);
     SD_REQUIRE(cfg->n_heads * cfg->head_dim == cfg->hidden, "sd_model_create: n_heads*head_dim != hidden");
     SD_REQUIRE(cfg->hidden % 4 == 0 && cfg->hidden <= 8192, "sd_model_create: hidden must be a multiple of 4 and <= 8192");
     SD_REQUIRE(cfg->n_kv_heads > 0 && cfg->n_heads % cfg->n_kv_heads == 0, "sd_model_create: bad n_kv_heads");
-    if (cfg->dtype == SD_BF16) {
+    if (is16(cfg->dtype)) {
         SD_REQUIRE(cfg->hidden % 32 == 0 && cfg->inter % 32 == 0 && cfg->vocab % 16 == 0 && cfg->opt_proj_dim % 32 == 0,
-                   "sd_model_create: bf16 path needs hidden/inter/proj %% 32 == 0 and vocab %% 16 == 0");
+                   "sd_model_create: the 16-bit paths need hidden/inter/proj %% 32 == 0 and vocab %% 16 == 0");
     }
     SD_REQUIRE(w->embed && w->lm_head && w->wqkv && w->wo && w->w_gate_up && w->w_down && w->norm1_w && w->norm2_w,
                "sd_model_create: missing weight pointers");
@@ -201,6 +204,7 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true) {
     return p;
 }
 
+template <typename H = bf16_t>
 static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, int Mpad, int N, int K,
                               const GemmPlan &pl, hipStream_t st) {
     const int MB = (Mpad / 16 + 2 * pl.mtw - 1) / (2 * pl.mtw), NB = N / 16 / 8;
@@ -208,22 +212,22 @@ static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, 
     const size_t lds = (size_t)2 * (8 + 2 * pl.mtw) * 2 * 1024;   // 2 buffers x (8 W + 2*MTW X tiles) x KT = 2 k-tiles
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<2, 4, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<2, 4, 2, H>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<4, 4, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_tiled<4, 4, 2, H>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
     if (pl.mtw == 2)
-        hipLaunchKernelGGL((gemm_bf16_tiled<2, 4, 2>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
+        hipLaunchKernelGGL((gemm_bf16_tiled<2, 4, 2, H>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
                            Mpad, N, K, pl.S, pl.ksp);
     else
-        hipLaunchKernelGGL((gemm_bf16_tiled<4, 4, 2>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
+        hipLaunchKernelGGL((gemm_bf16_tiled<4, 4, 2, H>), grid, dim3(256), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M,
                            Mpad, N, K, pl.S, pl.ksp);
 }
 
 static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
-    if (c.dtype != SD_BF16) return (size_t)rows * N;
+    if (!is16(c.dtype)) return (size_t)rows * N;
     size_t best = 0;
     for (int m = 1; m <= rows; m = (m % 16 == 0 ? m + 1 : (int)align_up(m, 16))) {       // every plan class: 1, 16, 17, 32, 33, ...
         const GemmPlan pl = gemm_plan(N, K, m);
@@ -285,7 +289,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
 extern "C" int sd_model_max_rows(const sd_model *m) {
     if (!m) return 0;
     const sd_model_config &c = m->cfg;
-    if (c.dtype != SD_BF16) return SD_MAX_FWD_ROWS;
+    if (!is16(c.dtype)) return SD_MAX_FWD_ROWS;
     const int ed = embed_dim(c);
     const int shapes[][2] = {{qkv_cols(c), c.hidden}, {c.hidden, c.hidden}, {gu_cols(c), c.hidden}, {c.hidden, c.inter},
                              {c.hidden, ed}, {ed, c.hidden}};
@@ -406,54 +410,55 @@ struct GemmOut {
     size_t stride_s;   // floats between k-slices
 };
 
-template <int MT, int EPI, int NTW>
+template <int MT, int EPI, int NTW, typename H = bf16_t>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
-                             int ks_per, const GemmEpi &e, hipStream_t st) {
+                             int ks_per, const GemmEpiT<H> &e, hipStream_t st) {
     const int blocks = (N / 16 / NTW) * S;
     constexpr int UNROLL = NTW >= 8 ? 1 : (MT > 2 ? 2 : 4);        // 4 measured best for decode rows (tools/gemm_bench.py)
-    hipLaunchKernelGGL((gemm_bf16_stream<MT, UNROLL, EPI, NTW>), dim3(blocks), dim3(256), 0, st,
-                       (const u32x4 *)W, (const bf16_t *)X, part, M, Mpad, N, K, S, ks_per, e);
+    hipLaunchKernelGGL((gemm_bf16_stream<MT, UNROLL, EPI, NTW, true, H>), dim3(blocks), dim3(256), 0, st,
+                       (const u32x4 *)W, (const H *)X, part, M, Mpad, N, K, S, ks_per, e);
 }
 
-template <int EPI>
+template <int EPI, typename H = bf16_t>
 static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
-                              int ksp, const GemmEpi &e, hipStream_t st) {
+                              int ksp, const GemmEpiT<H> &e, hipStream_t st) {
     const int MT = Mpad / 16;
     // rows beyond one m-tile (prefill, stream-batched verify): every activation fragment a wave loads is reused for
     // NTW weight tiles, because activations and weights share the CU's load path (X:W bytes = 16*MT : 16*NTW)
     const int ntw = gemm_ntw(N, M);
-    if (MT == 1) launch_gemm_bf16<1, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-    else if (MT == 2) { if (ntw >= 4) launch_gemm_bf16<2, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else if (ntw == 2) launch_gemm_bf16<2, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else launch_gemm_bf16<2, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
-    else if (MT == 3) { if (ntw == 8) launch_gemm_bf16<3, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else if (ntw == 4) launch_gemm_bf16<3, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else if (ntw == 2) launch_gemm_bf16<3, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else launch_gemm_bf16<3, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
-    else if (MT == 4) { if (ntw == 8) launch_gemm_bf16<4, EPI, 8>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else if (ntw == 4) launch_gemm_bf16<4, EPI, 4>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else if (ntw == 2) launch_gemm_bf16<4, EPI, 2>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
-                        else launch_gemm_bf16<4, EPI, 1>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
+    if (MT == 1) launch_gemm_bf16<1, EPI, 1, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+    else if (MT == 2) { if (ntw >= 4) launch_gemm_bf16<2, EPI, 4, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<2, EPI, 2, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<2, EPI, 1, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
+    else if (MT == 3) { if (ntw == 8) launch_gemm_bf16<3, EPI, 8, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 4) launch_gemm_bf16<3, EPI, 4, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<3, EPI, 2, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<3, EPI, 1, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
+    else if (MT == 4) { if (ntw == 8) launch_gemm_bf16<4, EPI, 8, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 4) launch_gemm_bf16<4, EPI, 4, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else if (ntw == 2) launch_gemm_bf16<4, EPI, 2, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st);
+                        else launch_gemm_bf16<4, EPI, 1, H>(W, X, part, M, Mpad, N, K, S, ksp, e, st); }
     else { sd_set_error("gemm: M=%d exceeds 64 rows per call", M); return SD_ERR_INVALID; }
     return SD_OK;
 }
 
 // X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> split-K slabs in s->part
+template <typename H = bf16_t>
 static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st,
                     const RowTab *xtab = nullptr) {
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
-    if (c.dtype == SD_BF16) {
+    if (is16(c.dtype)) {
         const GemmPlan pl = gemm_plan(N, K, M, xtab == nullptr);          // a row gather (lm_head) keeps the streaming kernel
         const int S = pl.S, ksp = pl.ksp;
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
         if (pl.tiled) {
-            launch_gemm_tiled(W, X, s->part, M, Mpad, N, K, pl, st);
+            launch_gemm_tiled<H>(W, X, s->part, M, Mpad, N, K, pl, st);
         } else {
-            GemmEpi e = {};
+            GemmEpiT<H> e = {};
             if (xtab) { e.use_xmap = 1; e.tab = *xtab; }
-            const int rc = dispatch_gemm_bf16<EPI_PART>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
+            const int rc = dispatch_gemm_bf16<EPI_PART, H>(W, X, s->part, M, Mpad, N, K, S, ksp, e, st);
             if (rc != SD_OK) return rc;
         }
         go->S = S;
@@ -470,12 +475,12 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
 }
 
 // bf16 GEMM whose workgroups keep the whole k-range (SB = 1) and finish with a fused epilogue
-template <int EPI>
-static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, int N, int K, const GemmEpi &e,
+template <int EPI, typename H = bf16_t>
+static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, int N, int K, const GemmEpiT<H> &e,
                           hipStream_t st) {
     ProfScope ps(s, PC_GEMM, st);
     const int Mpad = (int)align_up(M, 16);
-    const int rc = dispatch_gemm_bf16<EPI>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);
+    const int rc = dispatch_gemm_bf16<EPI, H>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);
     if (rc != SD_OK) return rc;
     SD_LAUNCH_CHECK();
     return SD_OK;
@@ -651,7 +656,7 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
         GemmEpi e = {};
         e.use_xmap = 1; e.tab = tab;
         SmallPro p = resid_pro(S_d, (const bf16_t *)m->bfc2[L - 1], m->w.final_norm_w, m->w.final_norm_b, false);
-        const int round_t = c.logits_bf16_round || (!llama && c.dtype == SD_BF16);
+        const int round_t = (c.logits_bf16_round || !llama) ? round_code(c.dtype) : 0;
         SD_REQUIRE((size_t)16 * c.vocab <= s->part_floats, "forward_small: logits slab too small");
         if (s->want_raw_logits && s->head_zero_rows && c.vocab % 16 == 0) {
             e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
@@ -676,6 +681,8 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
 template <typename T>
 static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits,
                         hipStream_t st) {
+    // 16-bit storage type of the MFMA GEMMs (the fp32 instantiation never launches them; it only has to compile)
+    using H16 = typename std::conditional<std::is_same<T, float>::value, bf16_t, T>::type;
     const int n_new = tab.n_rows, n_logits = tab.n_logit_rows;
     sd_model *m = s->m;
     const sd_model_config &c = m->cfg;
@@ -687,7 +694,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     const bool llama = c.arch == SD_ARCH_LLAMA;
     const int norm_kind = llama ? NORM_RMS : NORM_LN;
     const bool pre = llama || c.opt_pre_ln;
-    const bool fused = c.dtype == SD_BF16 && c.fused_layout != 0;
+    const bool fused = is16(c.dtype) && c.fused_layout != 0;
     T *x = (T *)s->x, *h = (T *)s->h, *qb = (T *)s->qbuf, *at = (T *)s->attn, *ac = (T *)s->act, *eb = (T *)s->ebuf;
     const size_t norm_lds = (size_t)(H + 32) * sizeof(float);
     const int pos_off = 2;                                                   // OPT offset (modeling_opt.py:104)
@@ -740,7 +747,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                                    (const T *)nullptr, 0, eb, 1, c.vocab);
                 SD_LAUNCH_CHECK();
             }
-            if ((rc = run_gemm(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
+            if ((rc = run_gemm<H16>(s, m->w.project_in, eb, n_new, H, ED, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_EMBED, st);
             hipLaunchKernelGGL((reduce_addpos_kernel<T>), dim3(n_new), dim3(256), 0, st, s->part, go.S, go.stride_s, H,
                                (const T *)m->w.pos_embed, tab, pos_off, x);
@@ -764,16 +771,16 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         // row count takes the tiled kernel, which leaves slabs for the stand-alone epilogue)
         if (l == 0 && qkv0_done) {
         } else if (fused && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
-            GemmEpi e = {};
-            e.out = (bf16_t *)qb; e.bias = (const bf16_t *)m->bqkv[l];
-            e.cos_t = (const bf16_t *)m->w.rope_cos; e.sin_t = (const bf16_t *)m->w.rope_sin;
+            GemmEpiT<H16> e = {};
+            e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
+            e.cos_t = (const H16 *)m->w.rope_cos; e.sin_t = (const H16 *)m->w.rope_sin;
             e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.layer = l; e.tab = tab;
             e.q_scale = 1.0f / sqrtf((float)D);
-            rc = llama ? run_gemm_fused<EPI_QKV_ROPE>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st)
-                       : run_gemm_fused<EPI_QKV_PLAIN>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st);
+            rc = llama ? run_gemm_fused<EPI_QKV_ROPE, H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st)
+                       : run_gemm_fused<EPI_QKV_PLAIN, H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, e, st);
             if (rc != SD_OK) return rc;
         } else {
-            if ((rc = run_gemm(s, m->wqkv[l], h, n_new, qkv_cols(c), H, &go, st)) != SD_OK) return rc;
+            if ((rc = run_gemm<H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_QKV, st);
             hipLaunchKernelGGL((qkv_epilogue_kernel<T>), dim3(n_new, c.n_heads + 2 * c.n_kv_heads),
                                dim3(std::max(D / 2, 64)), 0, st, s->part, go.S, go.stride_s, qkv_cols(c),
@@ -793,7 +800,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         // output projection + residual (+ norm feeding the MLP)
-        if ((rc = run_gemm(s, m->wo[l], at, n_new, H, H, &go, st)) != SD_OK) return rc;
+        if ((rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, H, &go, st)) != SD_OK) return rc;
         {
             ProfScope ps(s, PC_NORM, st);
             const int mode = pre ? RES_PRE : RES_POST;
@@ -805,19 +812,19 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         }
         // MLP
         if (fused && !gemm_plan(gu_cols(c), H, n_new).tiled) {
-            GemmEpi e = {};
-            e.out = (bf16_t *)ac; e.bias = (const bf16_t *)m->bfc1[l]; e.n_out = I;
-            rc = llama ? run_gemm_fused<EPI_ACT_SILU>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)
-                       : run_gemm_fused<EPI_ACT_RELU>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st);
+            GemmEpiT<H16> e = {};
+            e.out = (H16 *)ac; e.bias = (const H16 *)m->bfc1[l]; e.n_out = I;
+            rc = llama ? run_gemm_fused<EPI_ACT_SILU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)
+                       : run_gemm_fused<EPI_ACT_RELU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st);
             if (rc != SD_OK) return rc;
         } else {
-            if ((rc = run_gemm(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
+            if ((rc = run_gemm<H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, &go, st)) != SD_OK) return rc;
             ProfScope ps(s, PC_ACT, st);
             hipLaunchKernelGGL((act_kernel<T>), dim3((I + 255) / 256, n_new), dim3(256), 0, st, s->part, go.S,
                                go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
-        if ((rc = run_gemm(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
+        if ((rc = run_gemm<H16>(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
         {
             ProfScope ps(s, PC_NORM, st);
             int mode;
@@ -840,7 +847,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         const T *hl = h;
         const RowTab *xt = &tab;
         if (ED != H) {                                          // OPT project_out (modeling_opt.py:744-745)
-            if ((rc = run_gemm(s, m->w.project_out, hl, n_logits, ED, H, &go, st, xt)) != SD_OK) return rc;
+            if ((rc = run_gemm<H16>(s, m->w.project_out, hl, n_logits, ED, H, &go, st, xt)) != SD_OK) return rc;
             xt = nullptr;
             ProfScope ps(s, PC_LOGITS, st);
             hipLaunchKernelGGL((reduce_rows_kernel<T>), dim3((ED + 255) / 256, n_logits), dim3(256), 0, st, s->part,
@@ -848,24 +855,24 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
             hl = eb;
         }
-        const int round_t = c.logits_bf16_round || (!llama && c.dtype == SD_BF16);
+        const int round_t = (c.logits_bf16_round || !llama) ? round_code(c.dtype) : 0;
         // native iteration: the head also leaves the maximum of every 16-column tile and clears the probability rows, so
         // the normalisation that follows needs no candidate pass over V (EPI_HEAD; whole k-range per workgroup)
-        if (c.dtype == SD_BF16 && s->want_raw_logits && s->head_zero_rows && n_logits <= 16 && c.vocab % 16 == 0 &&
+        if (is16(c.dtype) && s->want_raw_logits && s->head_zero_rows && n_logits <= 16 && c.vocab % 16 == 0 &&
             gemm_plan(c.vocab, ED, n_logits, false).S == 1 && !gemm_plan(c.vocab, ED, n_logits, false).tiled) {
-            GemmEpi e = {};
+            GemmEpiT<H16> e = {};
             if (xt) { e.use_xmap = 1; e.tab = *xt; }
             e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
             {
                 ProfScope ps(s, PC_GEMM, st);
-                launch_gemm_bf16<1, EPI_HEAD, 1>(m->w.lm_head, hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
+                launch_gemm_bf16<1, EPI_HEAD, 1, H16>(m->w.lm_head, hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
                 SD_LAUNCH_CHECK();
             }
             s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
             s->last_tile_max = s->tile_max;
             return SD_OK;
         }
-        if ((rc = run_gemm(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
+        if ((rc = run_gemm<H16>(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
         if (s->want_raw_logits && go.S == 1) {
             s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
         } else {
@@ -920,6 +927,8 @@ static int launch_attn_bf16(sd_session *s, const bf16_t *q, const RowTab &tab, i
 static int run_forward(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits, void *stream) {
     if (s->m->cfg.dtype == SD_BF16)
         return forward_impl<bf16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+    if (s->m->cfg.dtype == SD_F16)
+        return forward_impl<f16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
     return forward_impl<float>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
 }
 
@@ -1056,7 +1065,8 @@ int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, i
 // SD_NORM_DT_* of a model's probability rows: OPT keeps logits and probabilities in the weight dtype
 // (modeling_opt.py:974), Llama casts its logits to fp32 (modeling_llama.py:870)
 static int storage_mode(const sd_model *m) {
-    return (m->cfg.arch == SD_ARCH_OPT && m->cfg.dtype == SD_BF16) ? SD_NORM_DT_BF16 : 0;
+    if (m->cfg.arch != SD_ARCH_OPT) return 0;
+    return m->cfg.dtype == SD_BF16 ? SD_NORM_DT_BF16 : (m->cfg.dtype == SD_F16 ? SD_NORM_DT_F16 : 0);
 }
 
 struct sd_spec {

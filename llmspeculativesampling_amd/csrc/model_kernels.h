@@ -7,8 +7,19 @@
 #include <type_traits>
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// D = A x B + C on a 16 x 16 x 32 tile for either 16-bit storage type H (bf16_t / f16_t): the two MFMA forms share the
+// operand layout and run at the same rate, so every kernel below is written once and instantiated per type.
+template <typename H>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (std::is_same<H, f16_t>::value)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // Row table of one forward, passed BY VALUE in the kernel arguments (no device copy to keep alive): rows may belong to
 // several independent sequences ("streams", SURVEY.md 8(e)/(f): stream-batched decode) that share the GEMMs and differ
@@ -59,11 +70,12 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4, EPI_HEAD = 5 };
 
 // Arguments of the fused epilogues (SB == 1: the workgroup holds the whole dot product after its LDS fold).
-struct GemmEpi {
-    bf16_t *out;              // ACT: act[M][n_out]            QKV: q buffer [M][Hq*D]
-    const bf16_t *bias;       // OPT biases (NULL for llama)
+template <typename H>
+struct GemmEpiT {
+    H *out;                   // ACT: act[M][n_out]            QKV: q buffer [M][Hq*D]
+    const H *bias;            // OPT biases (NULL for llama)
     int n_out;                // ACT: row stride of act (= inter)
-    const bf16_t *cos_t, *sin_t;
+    const H *cos_t, *sin_t;
     int Hq, Hkv, D, layer;    // QKV: K / V rows go to tab.kv_base[stream] + layer offset, at position tab.row_pos[m]
     float q_scale;
     int use_xmap;             // lm_head: activation row m is tab.xmap[m] of X
@@ -76,18 +88,20 @@ struct GemmEpi {
     long zero_ld;
     RowTab tab;
 };
+using GemmEpi = GemmEpiT<bf16_t>;
 
-__device__ __forceinline__ void store4(bf16_t *dst, float a, float b, float c, float d) {
-    const bf16_t v[4] = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+template <typename H>
+__device__ __forceinline__ void store4(H *dst, float a, float b, float c, float d) {
+    const H v[4] = {(H)a, (H)b, (H)c, (H)d};
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
 // One fold step of the streaming GEMMs' epilogue: red[wave][pp][lane] holds the 4 waves' accumulators of PT tiles; the
 // folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
 // gemm_small (small_kernels.h).
-template <int MT, int EPI, int NTW, int PT>
+template <int MT, int EPI, int NTW, int PT, typename H = bf16_t>
 __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
-                                                   int N, int sb, int ntg, const GemmEpi &e) {
+                                                   int N, int sb, int ntg, const GemmEpiT<H> &e) {
     auto folded = [&](int pp, int l) -> f32x4 {
         return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
     };
@@ -124,10 +138,10 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                 float a[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float gj = rnd<bf16_t>(g[c]), uj = rnd<bf16_t>(u[c]);
-                    a[c] = rnd<bf16_t>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
+                    const float gj = rnd<H>(g[c]), uj = rnd<H>(u[c]);
+                    a[c] = rnd<H>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
                 }
-                store4(e.out + xoff<bf16_t>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
+                store4(e.out + xoff<H>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
@@ -139,10 +153,10 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                 float a[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float f = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                    const float f = rnd<H>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
                     a[c] = f > 0.f ? f : 0.f;
                 }
-                store4(e.out + xoff<bf16_t>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
+                store4(e.out + xoff<H>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else {
@@ -157,26 +171,26 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                 const int head = col / e.D, within = col - head * e.D;
                 const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
                 const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
-                bf16_t *karena = (bf16_t *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
-                bf16_t *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
+                H *karena = (H *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
+                H *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
                                    : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
                                            : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
                 float x[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
+                for (int c = 0; c < 4; ++c) x[c] = rnd<H>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
                 if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         const int d = (within >> 1) + pr;
                         const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
                         const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
-                        dst[d] = (bf16_t)(rnd<bf16_t>(x0 * cs) + rnd<bf16_t>(-x1 * sn));
-                        dst[d + hd] = (bf16_t)(rnd<bf16_t>(x1 * cs) + rnd<bf16_t>(x0 * sn));
+                        dst[d] = (H)(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn));
+                        dst[d + hd] = (H)(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
                     }
                 } else {
                     if (EPI == EPI_QKV_PLAIN && is_q) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) x[c] = rnd<bf16_t>(x[c] * e.q_scale);
+                        for (int c = 0; c < 4; ++c) x[c] = rnd<H>(x[c] * e.q_scale);
                     }
                     store4(dst + within, x[0], x[1], x[2], x[3]);
                 }
@@ -185,10 +199,10 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
     }
 }
 
-template <int MT, int UNROLL, int EPI, int NTW, bool NT_LOADS = true>
-__global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
+template <int MT, int UNROLL, int EPI, int NTW, bool NT_LOADS = true, typename H = bf16_t>
+__global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict__ Wp, const H *__restrict__ X,
                                                        float *__restrict__ part, int M, int Mpad, int N, int K,
-                                                       int SB, int ks_per_blk, GemmEpi e) {
+                                                       int SB, int ks_per_blk, GemmEpiT<H> e) {
     // One workgroup = NTW consecutive 16-column n-tiles x one k-slab; its 4 waves take a quarter of the slab each
     // (every activation fragment a wave loads is reused for NTW weight tiles) and fold their accumulators through
     // LDS, so the number of partial slabs in HBM is SB, not 4*SB.  NTW = 1 for decode (M <= 16), 4 for prefill rows.
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
     for (int j = 0; j < NTW; ++j) wp[j] = Wp + ((size_t)(ntg * NTW + j) * KS + ks0) * 64 + lane;
     const int mrow = lane & 15, kq = (lane >> 4) * 8;
-    const bf16_t *xp[MT];
+    const H *xp[MT];
     bool mv[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -241,8 +255,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             for (int j = 0; j < NTW; ++j)
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u][j]),
-                                                                       __builtin_bit_cast(bf16x8, x[u][t]), acc[j][t], 0, 0, 0);
+                    acc[j][t] = mfma16<H>(w[u][j], x[u][t], acc[j][t]);
 #pragma unroll
         for (int j = 0; j < NTW; ++j) wp[j] += (size_t)UNROLL * 64;
 #pragma unroll
@@ -257,8 +270,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
             const u32x4 x = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t]) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j]),
-                                                                   __builtin_bit_cast(bf16x8, x), acc[j][t], 0, 0, 0);
+                acc[j][t] = mfma16<H>(w[j], x, acc[j][t]);
             xp[t] += xstep;
         }
     }
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) red[wv][pp][lane] = acc[(fs * PT + pp) / MT][(fs * PT + pp) % MT];
         __syncthreads();
-        gemm_epilogue_step<MT, EPI, NTW, PT>(red, fs, part, M, Mpad, N, sb, ntg, e);
+        gemm_epilogue_step<MT, EPI, NTW, PT, H>(red, fs, part, M, Mpad, N, sb, ntg, e);
     }
 }
 
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 // 2*NTWV MFMAs per global load instead of MTW / NTW in the streaming kernel.  No in-workgroup k-split: the k-range is
 // cut across workgroups (slabs) only when the block count is too small.
 // ------------------------------------------------------------------------------------------
-template <int MTW, int NTWV, int KT>
+template <int MTW, int NTWV, int KT, typename H = bf16_t>
 __global__ __launch_bounds__(256) void gemm_bf16_tiled(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
                                                       float *__restrict__ part, int M, int Mpad, int N, int K, int SB,
                                                       int ks_per_blk) {
@@ -345,8 +357,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tiled(const u32x4 *__restrict__
             for (int j = 0; j < NTWV; ++j)
 #pragma unroll
                 for (int t = 0; t < MTW; ++t)
-                    acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j]),
-                                                                       __builtin_bit_cast(bf16x8, xf[t]), acc[j][t], 0, 0, 0);
+                    acc[j][t] = mfma16<H>(wf[j], xf[t], acc[j][t]);
         }
         if (more) put(cur ^ 1);
         __syncthreads();
@@ -576,6 +587,12 @@ template <> __device__ __forceinline__ void store4t<float>(float *p, const float
     *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 template <> __device__ __forceinline__ void store4t<bf16_t>(bf16_t *p, const float (&v)[4]) { store4(p, v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t *p, float (&o)[4]) {
+    f16_t h[4];
+    *reinterpret_cast<uint2 *>(h) = *reinterpret_cast<const uint2 *>(p);
+    o[0] = (float)h[0]; o[1] = (float)h[1]; o[2] = (float)h[2]; o[3] = (float)h[3];
+}
+template <> __device__ __forceinline__ void store4t<f16_t>(f16_t *p, const float (&v)[4]) { store4(p, v[0], v[1], v[2], v[3]); }
 
 // Register-resident row: every thread owns RG groups of 4 consecutive columns (H <= 4*RG*blockDim), all of its loads
 // (split-K slabs, residual, bias, norm weights) are issued up front, and the only block-wide step is the reduction of
@@ -722,6 +739,12 @@ __device__ __forceinline__ void load8(const bf16_t *p, float (&o)[8]) {
         o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
     }
 }
+__device__ __forceinline__ void load8(const f16_t *p, float (&o)[8]) {
+    f16_t h[8];
+    *reinterpret_cast<u32x4 *>(h) = *reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+}
 __device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
     const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
@@ -734,6 +757,12 @@ template <> __device__ __forceinline__ void unpack8<bf16_t>(const u32x4 (&r)[1],
         o[2 * i] = __uint_as_float(r[0][i] << 16);
         o[2 * i + 1] = __uint_as_float(r[0][i] & 0xffff0000u);
     }
+}
+template <> __device__ __forceinline__ void unpack8<f16_t>(const u32x4 (&r)[1], float (&o)[8]) {
+    f16_t h[8];
+    *reinterpret_cast<u32x4 *>(h) = r[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
 }
 template <> __device__ __forceinline__ void unpack8<float>(const u32x4 (&r)[2], float (&o)[8]) {
 #pragma unroll
@@ -835,8 +864,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int dk = 0; dk < D / 32; ++dk)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kf[u][dk]),
-                                                                  __builtin_bit_cast(bf16x8, qf[dk]), acc, 0, 0, 0);
+                    acc = mfma16<T>(kf[u][dk], qf[dk], acc);
                 if (mrow < ATT_TQ) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {

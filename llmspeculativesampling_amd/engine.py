@@ -64,7 +64,7 @@ class SpecDecModel:
                  dtype: torch.dtype = torch.bfloat16, device: str = "cuda", max_pos: Optional[int] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("SpecDecModel needs a GPU: the HIP path has no CPU fallback")
-        assert dtype in (torch.float32, torch.bfloat16)
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.config = cfg
         self.cfg = cfg
         self.dtype = dtype
@@ -73,7 +73,7 @@ class SpecDecModel:
         self._keep: List[torch.Tensor] = []          # owns every device tensor the handle points into
         self._arrays = []
         self.weight_bytes = 0                        # bytes the forward streams (embedding tables excluded)
-        self.fused = dtype == torch.bfloat16 and cfg.intermediate_size % 8 == 0 and cfg.head_dim % 4 == 0
+        self.fused = dtype != torch.float32 and cfg.intermediate_size % 8 == 0 and cfg.head_dim % 4 == 0
         # dtype of the probability rows the reference would keep for this model (kvcache_model.py:167-168 on the model's
         # logits): OPT's logits stay in the weight dtype (modeling_opt.py:974), Llama's are cast to fp32 (:870)
         self.probs_dtype = dtype if cfg.arch == "opt" else torch.float32
@@ -90,7 +90,7 @@ class SpecDecModel:
         """[N][K] matrix -> device layout for the GEMM kernels."""
         t = t.to(device=self.device, dtype=self.dtype).contiguous()
         self.weight_bytes += t.numel() * t.element_size()
-        if self.dtype == torch.bfloat16:
+        if self.dtype != torch.float32:                       # bf16 / fp16: the tile layout is the same for both
             N, K = t.shape
             out = torch.empty_like(t)
             check(lib.sd_pack_weight_bf16(t.data_ptr(), out.data_ptr(), N, K, _stream()), "sd_pack_weight_bf16")
@@ -144,7 +144,7 @@ class SpecDecModel:
                 ang = torch.outer(torch.arange(self.max_pos, dtype=torch.float32), inv)
                 w.rope_cos = _ptr(self._dev(ang.cos()))
                 w.rope_sin = _ptr(self._dev(ang.sin()))
-                self.weight_bytes += (2 * L + 1) * cfg.hidden_size * (2 if self.dtype == torch.bfloat16 else 4)
+                self.weight_bytes += (2 * L + 1) * cfg.hidden_size * (4 if self.dtype == torch.float32 else 2)
             else:
                 d = "model.decoder."
                 emb = get(d + "embed_tokens.weight")
@@ -181,12 +181,12 @@ class SpecDecModel:
         w.norm2_w, w.norm2_b = self._ptr_array(n2w), self._ptr_array(n2b)
 
         c = _lib.SdModelConfig(
-            arch=cfg.arch_id, dtype=_lib.SD_BF16 if self.dtype == torch.bfloat16 else _lib.SD_F32,
+            arch=cfg.arch_id, dtype={torch.bfloat16: _lib.SD_BF16, torch.float16: _lib.SD_F16}.get(self.dtype, _lib.SD_F32),
             vocab=cfg.vocab_size, hidden=cfg.hidden_size, inter=cfg.intermediate_size, n_layers=L,
             n_heads=cfg.num_attention_heads, n_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
             max_pos=self.max_pos, opt_pre_ln=int(cfg.do_layer_norm_before), opt_proj_dim=cfg.word_embed_proj_dim or cfg.hidden_size,
             norm_eps=cfg.rms_norm_eps if cfg.arch == "llama" else cfg.layer_norm_eps,
-            logits_bf16_round=int(self.dtype == torch.bfloat16), fused_layout=int(self.fused))
+            logits_bf16_round=int(self.dtype != torch.float32), fused_layout=int(self.fused))
         h = C.c_void_p()
         check(lib.sd_model_create(C.byref(c), C.byref(w), C.byref(h)), "sd_model_create")
         self.handle = h
@@ -210,8 +210,10 @@ class SpecDecModel:
         evaluation.py:183-253 hands such modules to speculative_sampling)."""
         cfg = config_from_hf(module.config)
         sd = module.state_dict()
-        if dtype is None:
-            dtype = torch.bfloat16 if next(iter(sd.values())).dtype != torch.float32 else torch.float32
+        if dtype is None:                                 # the module's own dtype (the reference harness loads fp16)
+            dtype = next(iter(sd.values())).dtype
+            if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                dtype = torch.float32
         return cls(cfg, lambda n: sd[n], dtype=dtype, device=device, max_pos=max_pos)
 
     @classmethod
@@ -232,7 +234,7 @@ class SpecDecModel:
                 a = rng.standard_normal(size=shape, dtype=np.float32) * np.float32(std) + np.float32(mean)
                 return torch.from_numpy(a)
             gen.manual_seed(int(seed) * 100003 + idx)
-            t = torch.empty(shape, dtype=torch.float32 if dtype == torch.float32 else torch.bfloat16, device=device)
+            t = torch.empty(shape, dtype=dtype, device=device)
             return t.normal_(mean, std, generator=gen)
 
         def get(name: str) -> torch.Tensor:

@@ -506,3 +506,81 @@ def test_opt_bf16_pair_end_to_end_vs_oracle(hip):
     b, db = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 32, gamma=4, top_k=20, top_p=0.9, details=True,
                                        rng=hip.noise.DeviceNoise(9), verbose=True)
     assert torch.equal(a, b) and da["acc_len"] == db["acc_len"]
+
+
+# --------------------------------------------------------------------------- fp16 models (what the reference harness loads)
+FP16_CFGS = {
+    "llama_d64_gqa": dict(arch="llama", vocab_size=1024, hidden_size=256, intermediate_size=704, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-6),
+    "llama_d128": dict(arch="llama", vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=512, rms_norm_eps=1e-5),
+    "opt_d64_pre": dict(arch="opt", vocab_size=1024, hidden_size=128, ffn_dim=512, num_hidden_layers=2,
+                        num_attention_heads=2, max_position_embeddings=512, do_layer_norm_before=True, word_embed_proj_dim=128),
+    "opt_d32_post": dict(arch="opt", vocab_size=1024, hidden_size=128, ffn_dim=256, num_hidden_layers=2,
+                         num_attention_heads=4, max_position_embeddings=512, do_layer_norm_before=False, word_embed_proj_dim=64),
+}
+
+
+@pytest.mark.parametrize("name", list(FP16_CFGS))
+def test_fp16_forward_vs_oracle(hip, name):
+    """SD_F16: fp16 weights / activations / KV (the dtype evaluation.py:185 loads) through the same kernels as bf16
+    (v_mfma_f32_16x16x32_f16, fp32 accumulation, one rounding per op where the reference materialises a tensor) against
+    the oracle forward in fp16: prefill of 150 rows in chunks, then steps of 1, 2, 5 and 9 rows; KV rows likewise.
+    fp16 has 3 more mantissa bits than bf16: the bound is 8x tighter than the bf16 one."""
+    cfg = ModelConfig(**FP16_CFGS[name])
+    sd = make_state_dict(cfg, 77, dtype=torch.float16, gain=0.5)
+    om = oracle.RefCausalLM(cfg, sd)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float16)
+    ses = m.new_session(256)
+    assert ses.kv.dtype == torch.float16
+    ids = torch.from_numpy(np.random.default_rng(9).integers(3, cfg.vocab_size, size=(1, 167)))
+    past, pos = None, 0
+    for q in (150, 1, 2, 5, 9):
+        chunk = ids[:, pos:pos + q]
+        o = om(chunk, past_key_values=past)
+        past = o.past_key_values
+        nl = min(q, 9)
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), nl).cpu()
+        want = o.logits.float()[0, -nl:]
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 0.005 * scale + 2e-3, (name, q, float((got - want).abs().max()), scale)
+        pos += q
+    k, v = ses.past_key_values()[1]
+    ok, ov = past[1]
+    assert float((k.float().cpu() - ok.float()).abs().max()) <= 0.01 * max(1.0, float(ok.float().abs().max()))
+    assert float((v.float().cpu() - ov.float()).abs().max()) <= 0.01 * max(1.0, float(ov.float().abs().max()))
+
+
+def test_fp16_speculative_pair_and_hf_module(hip):
+    """fp16 end to end: a Llama pair (fp32 probability rows from fp16-rounded logits, SD_NORM_ROUND_F16) and an OPT pair
+    (fp16 probability rows, SD_NORM_DT_F16) against the oracle in fp16 under the same host seed; and a transformers
+    module in fp16 keeps its dtype through from_hf (it used to be converted to bf16)."""
+    import transformers
+    for arch in ("llama", "opt"):
+        cfg = ModelConfig(**FP16_CFGS["llama_d64_gqa" if arch == "llama" else "opt_d64_pre"])
+        dsd = make_state_dict(cfg, 5, dtype=torch.float16, gain=0.5)
+        tsd = {k: v.to(torch.float16) for k, v in perturb_state_dict({a: b.float() for a, b in dsd.items()}, 6, 0.05).items()}
+        prompt = torch.from_numpy(np.random.default_rng(3).integers(3, cfg.vocab_size, size=(1, 20)))
+        torch.manual_seed(31)
+        want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(cfg, dsd), oracle.RefCausalLM(cfg, tsd), 2, None, 32,
+                                               gamma=4, top_k=20, top_p=0.9, details=True)
+        dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.float16)
+        tm = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.float16)
+        assert dm.norm_mode == (hip.L.SD_NORM_DT_F16 if arch == "opt" else 0)
+        torch.manual_seed(31)
+        got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, 2, None, 32, gamma=4, top_k=20, top_p=0.9, details=True)
+        w, g = want[0].tolist(), got[0].cpu().tolist()
+        common = next((i for i, (a, b) in enumerate(zip(w, g)) if a != b), min(len(w), len(g)))
+        print(arch, "fp16: identical prefix", common - 20, "of", len(w) - 20, "generated tokens; acc_len", wd["acc_len"], gd["acc_len"])
+        assert common >= 20 + 8, (arch, common, w, g)
+        a, da = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 24, gamma=4, top_k=20, top_p=0.9, details=True,
+                                           rng=hip.noise.DeviceNoise(9))
+        b, db = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 24, gamma=4, top_k=20, top_p=0.9, details=True,
+                                           rng=hip.noise.DeviceNoise(9), verbose=True)
+        assert torch.equal(a, b) and da["acc_len"] == db["acc_len"]
+    lc = transformers.LlamaConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, intermediate_size=128, num_attention_heads=4,
+                                  num_key_value_heads=2, max_position_embeddings=128, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    torch.manual_seed(3)
+    mod = transformers.LlamaForCausalLM(lc).eval().half()
+    sm = hip.engine.as_specdec_model(mod)
+    assert sm.dtype == torch.float16 and sm.new_session(16).kv.dtype == torch.float16
