@@ -59,6 +59,10 @@ def parse(argv=None):
                     help="after the headline, time the same workload on the acceptance-dial pair at each --sweep-sigmas (N=1)")
     ap.add_argument("--sweep-sigmas", default="0,0.04,0.08,0.16,0.32,1.0")
     ap.add_argument("--sweep-steps", type=int, default=2)
+    ap.add_argument("--tp", type=int, default=1,
+                    help="tensor-parallel degree of the TARGET (BASELINE config 5: --target llama-2-70b --tp 8 --kv-dtype fp8): "
+                         "all --gpus ranks then decode ONE stream per step together (tp must equal gpus)")
+    ap.add_argument("--kv-dtype", default="model", choices=["model", "fp8"], help="dtype of the target's KV arena")
     return ap.parse_args(argv)
 
 
@@ -314,7 +318,23 @@ def main(argv=None):
     max_pos = args.prompt_len + args.max_len + args.gamma + 8
     t0 = time.time()
     dm = SpecDecModel.synthetic(dcfg, seed=1, dtype=torch.bfloat16, max_pos=max_pos)
-    tm = SpecDecModel.synthetic(tcfg, seed=2, dtype=torch.bfloat16, max_pos=max_pos)
+    TP = args.tp
+    if TP > 1:
+        # config 5: the target is ONE model sharded over all ranks (two RCCL all-reduces per layer); every rank runs the
+        # same stream with the same RNG seed, the draft is replicated
+        assert TP == world, f"--tp {TP} needs --gpus {TP}"
+        from llmspeculativesampling_amd import tp as tpmod
+
+        def bcast(b):
+            box = [b]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        group = tpmod.TPGroup.rccl(rank, world, bcast)
+        tm = tpmod.synthetic_shard(tcfg, rank, world, seed=2, group=group, dtype=torch.bfloat16, max_pos=max_pos)
+    else:
+        tm = SpecDecModel.synthetic(tcfg, seed=2, dtype=torch.bfloat16, max_pos=max_pos)
+    if args.kv_dtype == "fp8":
+        tm.kv_dtype = "fp8"
     torch.cuda.synchronize()
     t_build = time.time() - t0
 
@@ -347,20 +367,21 @@ def main(argv=None):
         return [out], d, int(out.shape[1]) - args.prompt_len
 
     # streams: rank r takes s = r, r+world, ... (round-robin)
+    srank, sworld = (0, 1) if TP > 1 else (rank, world)      # tensor parallel: one stream per step for the whole group
     for i in range(args.warmup):
-        run_step(rank + 10_000 * (i + 1))
+        run_step(srank + 10_000 * (i + 1))
     barrier()
     t0 = time.time()
     new_tokens, acc_sum, n_iters = 0, 0, 0
     logs = {"draft_ms": [], "target": []} if args.rng == "device" else ([], [])
     outs = []
     for i in range(args.steps):
-        o_list, d, n_new_tok = run_step(rank + i * world, logs)
+        o_list, d, n_new_tok = run_step(srank + i * sworld, logs)
         new_tokens += n_new_tok
         acc_sum += int(sum(d["acc_len"]))
         n_iters += int(d["target_call_times"])
         outs.extend(o_list)
-    if dist is not None:
+    if dist is not None and TP == 1:
         # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
         from llmspeculativesampling_amd.dist import gather_streams
         width = args.prompt_len + args.max_len + args.gamma + 1
@@ -374,6 +395,8 @@ def main(argv=None):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = stats[1:].clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if TP > 1:
+            tot /= world                              # every rank decoded the same streams: count them once
         elapsed, (new_tokens, acc_sum, n_iters) = float(tmax[0]), [float(x) for x in tot]
     value = new_tokens / elapsed
 
@@ -402,7 +425,7 @@ def main(argv=None):
         drf_ms = [e0.elapsed_time(e1) for (e0, e1, n_new, _) in logs[0] if n_new <= 2]
     t_ver = float(np.mean(ver_ms)) if ver_ms else float("nan")
     S_mean = float(np.mean(ver_S)) if ver_S else float(args.prompt_len + args.max_len / 2)
-    b_ver = algorithmic_verify_bytes(tcfg, args.gamma, S_mean)
+    b_ver = algorithmic_verify_bytes(tm.cfg if TP > 1 else tcfg, args.gamma, S_mean, kvbytes=1 if args.kv_dtype == "fp8" else 2)
     if BS > 1:       # one pass over the weights serves BS streams; KV and logits scale with the stream count
         w_only = tcfg.n_params(streamed_only=True) * 2
         b_ver = w_only * ((BS * (args.gamma + 1) + 63) // 64) + (b_ver - w_only) * BS
@@ -429,7 +452,7 @@ def main(argv=None):
     }
 
     # ---- per-op-class split of one verify step (events around every launch; outside the timed region)
-    if args.profile_classes and rank == 0 and BS == 1:
+    if args.profile_classes and rank == 0 and BS == 1 and TP == 1:
         ses = tm.new_session(max_pos)
         toks = prompt_for(0, tcfg.vocab_size, args.prompt_len + args.gamma + 1).cuda()[0].to(torch.int32)
         done = 0
@@ -460,18 +483,22 @@ def main(argv=None):
     result = {
         "metric": "accepted tokens/sec (speculative_sampling, llama-68m -> Llama-2-13b, gamma=4)",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if TP == 1 else "strong",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "scaling_note": None if TP == 1 else
+        "tensor-parallel target: the ranks decode the SAME stream together (strong scaling of one stream), per-rank roofline",
         "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt {args.prompt_len}, "
                                f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, {BS} stream(s) per step per GPU"
                                f"{' decoded in lockstep through shared weight passes' if BS > 1 else ''}, "
                                f"rng={args.rng}; random-init weights (accept-len ~0 by construction)",
-                   "streams": args.steps * world * BS, "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+                   "streams": args.steps * (1 if TP > 1 else world) * BS,
+                   "parallelism": (f"streams sharded over {world} GPU(s), no data-path collective" if TP == 1 else
+                                   f"target tensor-parallel over {TP} GPUs (2 RCCL all-reduces per layer), draft replicated"),
+                   "kv_dtype": args.kv_dtype},
         "mean_accept_len": acc_sum / max(1.0, n_iters), "iterations": n_iters, "new_tokens": new_tokens,
         "roofline": roofline, "model_build_s": t_build,
     }
 
-    if args.accept_sweep and rank == 0 and world == 1 and BS == 1 and dcfg.arch == "llama" and tcfg.arch == "llama":
+    if args.accept_sweep and rank == 0 and world == 1 and BS == 1 and args.kv_dtype == "model" and dcfg.arch == "llama" and tcfg.arch == "llama":
         try:
             result["acceptance_sweep"] = acceptance_sweep(args, dcfg, tcfg, max_pos)
         except Exception as e:

@@ -279,6 +279,11 @@ size_t sd_session_scratch_bytes(const sd_model *m, int max_rows);
 int sd_session_create(sd_model *m, int max_seq, int max_rows, void *kv_arena, void *scratch,
                       sd_session **out);
 int sd_session_destroy(sd_session *s);
+/* fp8 KV arena (BASELINE config 5): the arena then holds OCP e4m3 bytes, [n_layers][2][n_kv_heads][max_seq][head_dim],
+ * half the bytes of a 16-bit arena; `scales` = device floats [n_layers][2][n_kv_heads], an element x is stored as
+ * fp8(x / scale).  K / V rows are quantised where they are appended (the QKV epilogue, after RoPE), the attention kernel
+ * widens them back in registers.  16-bit models with head_dim >= 32; call before the first forward. */
+int sd_session_set_kv_fp8(sd_session *s, const float *scales);
 
 /* One model forward over n_new tokens at absolute positions pos0 .. pos0+n_new-1, appending their
  * K/V rows into the arena in-kernel (replaces the per-layer torch.cat of modeling_llama.py:337-338 /
@@ -324,6 +329,25 @@ int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_
 /* HIP-event timing of the draft phase and the target (verify) phase of the last iteration, on the launch stream. */
 int sd_spec_timing(sd_spec *sp, int on);
 int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms);
+
+/* ------------------------------------------------------------------------------------------
+ * Tensor parallelism of one decoder over the GPUs of a node (BASELINE config 5: Llama-2-70b, TP = 8 over xGMI).
+ * The reference is single-process: this is new capability behind the same call signatures.
+ * A shard is an ordinary sd_model whose config holds the LOCAL head / KV-head / MLP counts (n_heads * head_dim <= hidden)
+ * and whose matrices are the Megatron slices: wqkv / w_gate_up by output rows, wo / w_down by input columns.  A session
+ * bound to a group all-reduces the fp32 partial outputs of wo and w_down (two per layer) before the residual add.
+ * Every rank runs the same decode loop on the same tokens; draft model and sampling are replicated.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_tp sd_tp;
+/* RCCL group: rank 0 obtains a 128-byte id and the host broadcasts it (torch.distributed / any side channel); every
+ * rank then joins.  RCCL is resolved with dlopen on first use (the copy the process already holds, if any). */
+int sd_tp_unique_id(void *id128);
+int sd_tp_create_rccl(int rank, int world, const void *id128, sd_tp **out);
+/* Loopback group: `world` ranks inside ONE process on one GPU (each driven by its own host thread and stream; the
+ * all-reduce is an event-ordered rendezvous + a sum kernel).  For testing the sharded forward on a one-GPU box. */
+int sd_tp_create_loopback(int world, sd_tp **out /* world handles */);
+int sd_tp_destroy(sd_tp *t);
+int sd_session_set_tp(sd_session *s, sd_tp *t);
 
 /* Per-op-class timing for the roofline report: when enabled, every launch inside
  * sd_session_forward is bracketed with HIP events on the launch stream; sd_profile_read

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("sd_session_scratch_bytes", C.c_size_t, [_VP, _I]),
     ("sd_session_create", _I, [_VP, _I, _I, _VP, _VP, C.POINTER(_VP)]),
     ("sd_session_destroy", _I, [_VP]),
+    ("sd_session_set_kv_fp8", _I, [_VP, _VP]),
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
     ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),
     ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
@@ -106,6 +107,11 @@ SYMBOLS = [
     ("sd_spec_iteration", _I, [_VP, _I, _I, _I, _U64, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_spec_timing", _I, [_VP, _I]),
     ("sd_spec_last_times", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("sd_tp_unique_id", _I, [_VP]),
+    ("sd_tp_create_rccl", _I, [_I, _I, _VP, C.POINTER(_VP)]),
+    ("sd_tp_create_loopback", _I, [_I, C.POINTER(_VP)]),
+    ("sd_tp_destroy", _I, [_VP]),
+    ("sd_session_set_tp", _I, [_VP, _VP]),
     ("sd_profile_enable", _I, [_VP, _I]),
     ("sd_profile_read", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 ]

@@ -39,6 +39,9 @@ class ModelConfig:
     # the reference branches on this attribute (speculative_sampling.py:1942,1955)
     is_encoder_decoder: bool = False
     name: str = ""
+    # width of one attention head when it is not hidden_size / num_attention_heads: a tensor-parallel shard keeps the
+    # model's hidden size but only a slice of its heads (tp.py)
+    head_dim_: int = 0
 
     def __post_init__(self):
         if self.arch == "llama":
@@ -51,12 +54,12 @@ class ModelConfig:
             self.intermediate_size = self.ffn_dim
         else:
             raise ValueError(f"unknown arch {self.arch!r}")
-        if self.hidden_size % self.num_attention_heads:
+        if not self.head_dim_ and self.hidden_size % self.num_attention_heads:
             raise ValueError("hidden_size must be divisible by num_attention_heads")
 
     @property
     def head_dim(self) -> int:
-        return self.hidden_size // self.num_attention_heads
+        return self.head_dim_ or self.hidden_size // self.num_attention_heads
 
     @property
     def arch_id(self) -> int:
@@ -71,7 +74,8 @@ class ModelConfig:
         h, L, V = self.hidden_size, self.num_hidden_layers, self.vocab_size
         if self.arch == "llama":
             kv = self.num_key_value_heads * self.head_dim
-            per = h * h * 2 + 2 * h * kv + 3 * h * self.intermediate_size + 2 * h
+            qd = self.num_attention_heads * self.head_dim           # == h unless this is a tensor-parallel shard
+            per = h * qd * 2 + 2 * h * kv + 3 * h * self.intermediate_size + 2 * h
             n = per * L + h + V * h          # final norm + lm_head
             if not streamed_only:
                 n += V * h                   # embed_tokens (untied)

@@ -40,6 +40,10 @@ struct sd_session {
     float *spart;       // split-K slabs of the small-model path's O / down GEMMs (its head writes s->part meanwhile)
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
+    int kv_fp8;         // the arena holds fp8 e4m3 (sd_session_set_kv_fp8)
+    const float *kv_scale;   // device [L][2][Hkv]
+    struct sd_tp *tp;   // tensor-parallel group of this shard (NULL: the model is whole)
+    float *tp_in, *tp_out;   // [max_rows][hidden] fp32: this rank's partial O / down output, and the all-reduced sum
     float *attn_part;   // [groups*splits <= 64][Hq][TQ][D+2] partial attention sums of the split-key path
     float *part;
     size_t part_floats;
@@ -82,7 +86,9 @@ extern "C" int sd_model_create(const sd_model_config *cfg, const sd_model_weight
     SD_REQUIRE(cfg->dtype == SD_F32 || cfg->dtype == SD_BF16 || cfg->dtype == SD_F16, "sd_model_create: unknown dtype %d", cfg->dtype);
     SD_REQUIRE(cfg->head_dim == 16 || cfg->head_dim == 32 || cfg->head_dim == 64 || cfg->head_dim == 128,
                "sd_model_create: head_dim %d not in {16,32,64,128}", cfg->head_dim);
-    SD_REQUIRE(cfg->n_heads * cfg->head_dim == cfg->hidden, "sd_model_create: n_heads*head_dim != hidden");
+    // a tensor-parallel shard holds n_heads / world query heads: its attention width is a fraction of hidden
+    SD_REQUIRE(cfg->n_heads * cfg->head_dim <= cfg->hidden && (cfg->n_heads * cfg->head_dim) % 32 == 0,
+               "sd_model_create: n_heads*head_dim must be <= hidden and a multiple of 32");
     SD_REQUIRE(cfg->hidden % 4 == 0 && cfg->hidden <= 8192, "sd_model_create: hidden must be a multiple of 4 and <= 8192");
     SD_REQUIRE(cfg->n_kv_heads > 0 && cfg->n_heads % cfg->n_kv_heads == 0, "sd_model_create: bad n_kv_heads");
     if (is16(cfg->dtype)) {
@@ -237,6 +243,7 @@ static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows)
 }
 
 static int qkv_cols(const sd_model_config &c) { return (c.n_heads + 2 * c.n_kv_heads) * c.head_dim; }
+static int q_dim(const sd_model_config &c) { return c.n_heads * c.head_dim; }     // attention width (== hidden unless sharded)
 static int gu_cols(const sd_model_config &c) { return c.arch == SD_ARCH_LLAMA ? 2 * c.inter : c.inter; }
 static int embed_dim(const sd_model_config &c) { return c.arch == SD_ARCH_OPT ? c.opt_proj_dim : c.hidden; }
 
@@ -246,7 +253,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, q, attn, act, e, apart, part, spart, tmax, total, part_floats, spart_floats;
+    size_t x, x2, h, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -266,7 +273,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.apart = take((size_t)64 * c.n_heads * 8 * (c.head_dim + 2) * sizeof(float));
     size_t pf = 0;
     pf = std::max(pf, gemm_part_floats(c, qkv_cols(c), c.hidden, rows));
-    pf = std::max(pf, gemm_part_floats(c, c.hidden, c.hidden, rows));
+    pf = std::max(pf, gemm_part_floats(c, c.hidden, q_dim(c), rows));
     pf = std::max(pf, gemm_part_floats(c, gu_cols(c), c.hidden, rows));
     pf = std::max(pf, gemm_part_floats(c, c.hidden, c.inter, rows));
     pf = std::max(pf, gemm_part_floats(c, c.vocab, ed, rows));
@@ -280,6 +287,8 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.spart_floats = (size_t)16 * 16 * c.hidden;
     p.spart = take(p.spart_floats * sizeof(float));
     p.tmax = take((size_t)SD_MAX_ROWS * (c.vocab / 16 + 1) * sizeof(float));
+    p.tp_in = take((size_t)rows * c.hidden * sizeof(float));
+    p.tp_out = take((size_t)rows * c.hidden * sizeof(float));
     p.total = off;
     return p;
 }
@@ -291,7 +300,7 @@ extern "C" int sd_model_max_rows(const sd_model *m) {
     const sd_model_config &c = m->cfg;
     if (!is16(c.dtype)) return SD_MAX_FWD_ROWS;
     const int ed = embed_dim(c);
-    const int shapes[][2] = {{qkv_cols(c), c.hidden}, {c.hidden, c.hidden}, {gu_cols(c), c.hidden}, {c.hidden, c.inter},
+    const int shapes[][2] = {{qkv_cols(c), c.hidden}, {c.hidden, q_dim(c)}, {gu_cols(c), c.hidden}, {c.hidden, c.inter},
                              {c.hidden, ed}, {ed, c.hidden}};
     for (int i = 0; i < (ed != c.hidden ? 6 : 4); ++i)
         if (!gemm_plan(shapes[i][0], shapes[i][1], SD_MAX_FWD_ROWS).tiled) return SD_MAX_ROWS;
@@ -323,6 +332,11 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->spart = (float *)(s->scratch + p.spart);
     s->spart_floats = p.spart_floats;
     s->tile_max = (float *)(s->scratch + p.tmax);
+    s->tp = nullptr;
+    s->kv_fp8 = 0;
+    s->kv_scale = nullptr;
+    s->tp_in = (float *)(s->scratch + p.tp_in);
+    s->tp_out = (float *)(s->scratch + p.tp_out);
     s->head_zero_rows = nullptr;
     s->head_zero_ld = 0;
     s->last_tile_max = nullptr;
@@ -342,6 +356,17 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     memset(s->prof_ms, 0, sizeof(s->prof_ms));
     memset(s->prof_cnt, 0, sizeof(s->prof_cnt));
     *out = s;
+    return SD_OK;
+}
+
+// Switch the session's KV arena to OCP fp8 e4m3 (BASELINE config 5).  The arena then holds 1 byte per element
+// (half of sd_session_kv_bytes for a 16-bit model); `scales` is a device array [n_layers][2][n_kv_heads] (x is stored as
+// fp8(x / scale)); call before the first forward.
+extern "C" int sd_session_set_kv_fp8(sd_session *s, const float *scales) {
+    SD_REQUIRE(s && scales, "sd_session_set_kv_fp8: null argument");
+    SD_REQUIRE(is16(s->m->cfg.dtype) && s->m->cfg.head_dim >= 32, "sd_session_set_kv_fp8: needs a 16-bit model with head_dim >= 32");
+    s->kv_fp8 = 1;
+    s->kv_scale = scales;
     return SD_OK;
 }
 
@@ -404,11 +429,188 @@ extern "C" int sd_profile_read(sd_session *s, float *ms_out, int *count_out) {
     return SD_OK;
 }
 
-// ---- launch helpers ----------------------------------------------------------------------
+
+// ---- tensor parallelism (BASELINE config 5: Llama-2-70b over 8 GPUs) ---------------------------------
+// Megatron-style sharding of one decoder: QKV and gate/up split by output columns (each rank owns n_heads / world query
+// heads, n_kv_heads / world KV heads and inter / world MLP columns), O and down split by input rows, so a layer needs two
+// all-reduces of the [rows][hidden] partial outputs (fp32: the sum is rounded to the model dtype once, like an unsharded
+// dot product).  At gamma + 1 = 5 rows x 8192 that is 160 KB: latency-bound on xGMI, RCCL picks its low-latency
+// protocol on its own for such sizes.  The reference has no counterpart (it is single-process); the math
+// follows modeling_llama.py:292-393 with pretraining_tp = 1.
+//   * RCCL group: one process per GPU, the communicator is created from a unique id the host broadcasts;
+//     the library is resolved with dlopen at first use (a process that already holds RCCL - torch does - shares it).
+//   * loopback group: all ranks live in ONE process on one GPU, each in its own host thread and stream; the all-reduce
+//     is two event-ordered rendezvous and a sum kernel.  It exists so that the sharded forward can be tested on a
+//     one-GPU box (tests/test_gpu_native_parity.py) with the very kernels the RCCL path runs.
+#include <dlfcn.h>
+#include <condition_variable>
+#include <mutex>
+
 struct GemmOut {
     int S;
     size_t stride_s;   // floats between k-slices
 };
+
+struct TpLoop {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long gen = 0;
+    const float *bufs[16];
+    hipEvent_t ev_in[16], ev_out[16];
+    int refs = 0;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long g = gen;
+        if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+struct sd_tp {
+    int rank, world;
+    void *comm;          // ncclComm_t
+    TpLoop *loop;
+};
+
+typedef int (*nccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_getid_fn)(void *);
+struct sd_nccl_id { char b[128]; };                  // ncclUniqueId is passed by value
+typedef int (*nccl_initrank_fn)(void **, int, sd_nccl_id, int);
+typedef int (*nccl_destroy_fn)(void *);
+static struct { void *lib; nccl_allreduce_fn allreduce; nccl_getid_fn getid; nccl_initrank_fn initrank; nccl_destroy_fn destroy; } g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return SD_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy this process already holds, if any
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { sd_set_error("tensor parallelism needs RCCL: %s", dlerror()); return SD_ERR_HIP; }
+    g_rccl.allreduce = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+    g_rccl.getid = (nccl_getid_fn)dlsym(h, "ncclGetUniqueId");
+    g_rccl.initrank = (nccl_initrank_fn)dlsym(h, "ncclCommInitRank");
+    g_rccl.destroy = (nccl_destroy_fn)dlsym(h, "ncclCommDestroy");
+    if (!g_rccl.allreduce || !g_rccl.getid || !g_rccl.initrank || !g_rccl.destroy) {
+        sd_set_error("RCCL is missing ncclAllReduce / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy");
+        return SD_ERR_HIP;
+    }
+    g_rccl.lib = h;
+    return SD_OK;
+}
+
+extern "C" int sd_tp_unique_id(void *id128) {
+    SD_REQUIRE(id128, "sd_tp_unique_id: null buffer");
+    int rc = rccl_load();
+    if (rc != SD_OK) return rc;
+    if (g_rccl.getid(id128) != 0) { sd_set_error("ncclGetUniqueId failed"); return SD_ERR_HIP; }
+    return SD_OK;
+}
+
+extern "C" int sd_tp_create_rccl(int rank, int world, const void *id128, sd_tp **out) {
+    SD_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, "sd_tp_create_rccl: bad arguments");
+    int rc = rccl_load();
+    if (rc != SD_OK) return rc;
+    sd_nccl_id id;
+    memcpy(id.b, id128, 128);
+    void *comm = nullptr;
+    if (g_rccl.initrank(&comm, world, id, rank) != 0) { sd_set_error("ncclCommInitRank(rank %d of %d) failed", rank, world); return SD_ERR_HIP; }
+    sd_tp *t = new sd_tp{rank, world, comm, nullptr};
+    *out = t;
+    return SD_OK;
+}
+
+extern "C" int sd_tp_create_loopback(int world, sd_tp **out /* world handles */) {
+    SD_REQUIRE(out && world >= 1 && world <= 16, "sd_tp_create_loopback: 1..16 ranks");
+    TpLoop *L = new TpLoop();
+    L->world = world;
+    L->refs = world;
+    for (int r = 0; r < world; ++r) {
+        SD_HIP_CHECK(hipEventCreateWithFlags(&L->ev_in[r], hipEventDisableTiming));
+        SD_HIP_CHECK(hipEventCreateWithFlags(&L->ev_out[r], hipEventDisableTiming));
+        out[r] = new sd_tp{r, world, nullptr, L};
+    }
+    return SD_OK;
+}
+
+extern "C" int sd_tp_destroy(sd_tp *t) {
+    if (!t) return SD_OK;
+    if (t->comm && g_rccl.destroy) g_rccl.destroy(t->comm);
+    if (t->loop) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(t->loop->mu); last = --t->loop->refs == 0; }
+        if (last) {
+            for (int r = 0; r < t->loop->world; ++r) { (void)hipEventDestroy(t->loop->ev_in[r]); (void)hipEventDestroy(t->loop->ev_out[r]); }
+            delete t->loop;
+        }
+    }
+    delete t;
+    return SD_OK;
+}
+
+extern "C" int sd_session_set_tp(sd_session *s, sd_tp *t) {
+    SD_REQUIRE(s, "sd_session_set_tp: null session");
+    s->tp = (t && t->world > 1) ? t : nullptr;
+    return SD_OK;
+}
+
+// tp_in[i] = sum_s part[s][i]  (rows are M x N contiguous at the start of every slab)
+__global__ void tp_fold_kernel(const float *__restrict__ part, int S, size_t stride_s, int total, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) a += part[(size_t)s2 * stride_s + i];
+    out[i] = a;
+}
+struct TpBufs { const float *p[16]; };
+__global__ void tp_sum_kernel(TpBufs b, int world, int total, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a = 0.f;
+    for (int r = 0; r < world; ++r) a += b.p[r][i];          // fixed rank order: every rank gets the same bits
+    out[i] = a;
+}
+
+// After a row-parallel GEMM: fold this rank's k-slabs, all-reduce the [M][N] fp32 partial over the group and point the
+// residual epilogue at the sum (one slab).  No-op without a group.
+static int tp_reduce(sd_session *s, GemmOut *go, const float **src, int M, int N, hipStream_t st) {
+    sd_tp *t = s->tp;
+    if (!t) return SD_OK;
+    const int total = M * N;
+    {
+        ProfScope ps(s, PC_OTHER, st);
+        hipLaunchKernelGGL(tp_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, *src, go->S, go->stride_s, total, s->tp_in);
+        SD_LAUNCH_CHECK();
+        if (t->comm) {
+            if (g_rccl.allreduce(s->tp_in, s->tp_out, (size_t)total, /* ncclFloat32 */ 7, /* ncclSum */ 0, t->comm, st) != 0) {
+                sd_set_error("ncclAllReduce failed");
+                return SD_ERR_HIP;
+            }
+        } else {
+            TpLoop *L = t->loop;
+            L->bufs[t->rank] = s->tp_in;
+            SD_HIP_CHECK(hipEventRecord(L->ev_in[t->rank], st));
+            L->barrier();                                           // every rank's partial is enqueued
+            TpBufs b = {};
+            for (int r = 0; r < t->world; ++r) {
+                b.p[r] = L->bufs[r];
+                if (r != t->rank) SD_HIP_CHECK(hipStreamWaitEvent(st, L->ev_in[r], 0));
+            }
+            hipLaunchKernelGGL(tp_sum_kernel, dim3((total + 255) / 256), dim3(256), 0, st, b, t->world, total, s->tp_out);
+            SD_LAUNCH_CHECK();
+            SD_HIP_CHECK(hipEventRecord(L->ev_out[t->rank], st));
+            L->barrier();                                           // nobody overwrites its partial before all have read it
+            for (int r = 0; r < t->world; ++r)
+                if (r != t->rank) SD_HIP_CHECK(hipStreamWaitEvent(st, L->ev_out[r], 0));
+        }
+    }
+    *src = s->tp_out;
+    go->S = 1;
+    go->stride_s = 0;
+    return SD_OK;
+}
+
+// ---- launch helpers ----------------------------------------------------------------------
 
 template <int MT, int EPI, int NTW, typename H = bf16_t>
 static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, int S,
@@ -516,11 +718,20 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
     }
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if constexpr (sizeof(T) == 2 && D >= 32)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_kernel<T, D>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer, out,
+    if (tab.kv_fp8) {
+        if constexpr (sizeof(T) == 2 && D >= 32)
+            hipLaunchKernelGGL((attn_kernel<T, D, true>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer,
+                               out, c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
+        else { sd_set_error("fp8 KV needs a 16-bit model with head_dim >= 32"); return SD_ERR_INVALID; }
+    } else
+    hipLaunchKernelGGL((attn_kernel<T, D, false>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer, out,
                        c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
     if (nsplit > 1)
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3(c.n_heads, tab.n_groups), dim3(128), 0, st,
@@ -534,7 +745,7 @@ static bool small_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
     const char *env = getenv("SD_SMALL_PATH");                         // (read per call: the tests flip it in-process)
     const int enabled = env ? atoi(env) : 0;      // off by default: measured slower than the per-op chain
-    if (!enabled || c.dtype != SD_BF16 || !c.fused_layout || tab.contig) return false;
+    if (!enabled || c.dtype != SD_BF16 || !c.fused_layout || tab.contig || s->tp) return false;
     if (tab.n_rows > SMALL_MAX_ROWS || tab.n_logit_rows > SMALL_MAX_ROWS) return false;
     if (c.hidden > 2048 || c.hidden % 32 != 0 || embed_dim(c) != c.hidden) return false;
     if (c.arch == SD_ARCH_OPT && !c.opt_pre_ln) return false;          // post-LN keeps the stand-alone norm launches
@@ -584,7 +795,7 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
     int cur = 0;                                                   // R[cur] holds the residual stream
     int rc;
     int S_o, ksp_o, S_d, ksp_d;
-    small_split(H, H, &S_o, &ksp_o);
+    small_split(H, q_dim(c), &S_o, &ksp_o);
     small_split(H, I, &S_d, &ksp_d);
     SD_REQUIRE((size_t)std::max(S_o, S_d) * 16 * H <= s->spart_floats, "forward_small: slab buffer too small");
 
@@ -631,7 +842,7 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
         {
             GemmEpi e = {};
             SmallPro p = {};
-            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wo[l], at, s->spart, M, H, H, S_o, ksp_o, e, p, st)) != SD_OK) return rc;
+            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wo[l], at, s->spart, M, H, q_dim(c), S_o, ksp_o, e, p, st)) != SD_OK) return rc;
         }
         // ---- gate/up (fc1): prologue = O slabs + residual + post-attention norm; epilogue = SiLU * up / ReLU
         {
@@ -800,13 +1011,15 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         // output projection + residual (+ norm feeding the MLP)
-        if ((rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, H, &go, st)) != SD_OK) return rc;
+        if ((rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
+        const float *osrc = s->part;
+        if ((rc = tp_reduce(s, &go, &osrc, n_new, H, st)) != SD_OK) return rc;
         {
             ProfScope ps(s, PC_NORM, st);
             const int mode = pre ? RES_PRE : RES_POST;
             const T *nw = pre ? (const T *)m->n2w[l] : (const T *)m->n1w[l];
             const T *nb = pre ? (const T *)m->n2b[l] : (const T *)m->n1b[l];
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, osrc, go.S,
                                go.stride_s, H, (const T *)m->bo[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }
@@ -825,6 +1038,8 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         if ((rc = run_gemm<H16>(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
+        const float *dsrc = s->part;
+        if ((rc = tp_reduce(s, &go, &dsrc, n_new, H, st)) != SD_OK) return rc;
         {
             ProfScope ps(s, PC_NORM, st);
             int mode;
@@ -836,7 +1051,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             } else {
                 mode = RES_POST; nw = (const T *)m->n2w[l]; nb = (const T *)m->n2b[l];
             }
-            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, s->part, go.S,
+            hipLaunchKernelGGL((residual_norm_kernel<T>), dim3(n_new), dim3(rn_threads), 0, st, x, dsrc, go.S,
                                go.stride_s, H, (const T *)m->bfc2[l], nw, nb, c.norm_eps, norm_kind, mode, h);
             SD_LAUNCH_CHECK();
         }
@@ -950,6 +1165,8 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     tab.tok_base[0] = tokens - pos0;            // indexed by absolute position, only ever read at pos0 .. pos0+n_new-1
     tab.kv_base[0] = s->kv;
     tab.max_seq[0] = s->max_seq;
+    tab.kv_fp8 = s->kv_fp8;
+    tab.kv_scale[0] = s->kv_scale;
     if (n_new > SD_MAX_ROWS) {                      // prefill chunk: positions are implicit
         tab.contig = 1;
         tab.pos0 = pos0;
@@ -982,9 +1199,12 @@ extern "C" int sd_batch_forward(const sd_batch_item *items, int n_items, float *
                          std::min(s0->max_rows, SD_MAX_ROWS), it.pos0 + it.n_new, it.session->max_seq);
             return SD_ERR_CAPACITY;
         }
+        SD_REQUIRE(it.session->kv_fp8 == s0->kv_fp8, "sd_batch_forward: item %d: KV arenas of different dtypes", i);
         tab.tok_base[i] = it.seq;
         tab.kv_base[i] = it.session->kv;
         tab.max_seq[i] = it.session->max_seq;
+        tab.kv_fp8 = it.session->kv_fp8;
+        tab.kv_scale[i] = it.session->kv_scale;
         for (int r = 0; r < it.n_new; ++r) {
             tab.row_pos[rows + r] = it.pos0 + r;
             tab.row_stream[rows + r] = (unsigned char)i;

@@ -38,6 +38,8 @@ struct RowTab {
     const int32_t *tok_base[SD_MAX_STREAMS];        // stream's token buffer, indexed by absolute position
     void *kv_base[SD_MAX_STREAMS];                  // stream's KV arena [L][2][Hkv][max_seq][D]
     int max_seq[SD_MAX_STREAMS];                    // that arena's capacity
+    int kv_fp8;                                     // the arenas hold OCP fp8 e4m3 (1 byte per element) instead of T
+    const float *kv_scale[SD_MAX_STREAMS];          // fp8: per (layer, k|v, kv head) scales [L][2][Hkv], x = fp8 * scale
     // attention groups: <= ATT_TQ consecutive rows of one stream (first row, count, position of the first row, stream)
     int grp_row0[SD_MAX_GROUPS], grp_n[SD_MAX_GROUPS], grp_pos[SD_MAX_GROUPS], grp_stream[SD_MAX_GROUPS];
 };
@@ -70,6 +72,33 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4, EPI_HEAD = 5 };
 
 // Arguments of the fused epilogues (SB == 1: the workgroup holds the whole dot product after its LDS fold).
+// ---- fp8 (OCP e4m3, gfx950's native form) KV arena: x is stored as fp8(x / scale), read back as fp8 * scale.  The
+// attention kernel folds the K scale into the scores and the V scale into the output, so the fp8 -> 16-bit conversion of a
+// key / value element is exact (3 mantissa bits fit either 16-bit type).
+__device__ __forceinline__ unsigned char to_fp8(float x, float inv_scale) {
+    const float v = fminf(fmaxf(x * inv_scale, -448.f), 448.f);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
+__device__ __forceinline__ void store4_fp8(unsigned char *dst, float a, float b, float c, float d, float inv_scale) {
+    const float lo = -448.f, hi = 448.f;
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(a * inv_scale, lo), hi), fminf(fmaxf(b * inv_scale, lo), hi), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c * inv_scale, lo), hi), fminf(fmaxf(d * inv_scale, lo), hi), w, true);
+    *reinterpret_cast<int *>(dst) = w;
+}
+// 8 consecutive fp8 elements -> 8 elements of the 16-bit type T packed as the MFMA operand / the P.V unpack expects
+template <typename T>
+__device__ __forceinline__ u32x4 fp8x8_to_16(uint2 raw) {
+    float f[8];
+    f[0] = __builtin_amdgcn_cvt_f32_fp8((int)raw.x, 0); f[1] = __builtin_amdgcn_cvt_f32_fp8((int)raw.x, 1);
+    f[2] = __builtin_amdgcn_cvt_f32_fp8((int)raw.x, 2); f[3] = __builtin_amdgcn_cvt_f32_fp8((int)raw.x, 3);
+    f[4] = __builtin_amdgcn_cvt_f32_fp8((int)raw.y, 0); f[5] = __builtin_amdgcn_cvt_f32_fp8((int)raw.y, 1);
+    f[6] = __builtin_amdgcn_cvt_f32_fp8((int)raw.y, 2); f[7] = __builtin_amdgcn_cvt_f32_fp8((int)raw.y, 3);
+    T h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (T)f[i];
+    return *reinterpret_cast<const u32x4 *>(h);
+}
+
 template <typename H>
 struct GemmEpiT {
     H *out;                   // ACT: act[M][n_out]            QKV: q buffer [M][Hq*D]
@@ -171,10 +200,13 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                 const int head = col / e.D, within = col - head * e.D;
                 const bool is_q = head < e.Hq, is_k = !is_q && head < e.Hq + e.Hkv;
                 const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
-                H *karena = (H *)e.tab.kv_base[strm] + (size_t)e.layer * 2 * e.Hkv * mseq * e.D;
-                H *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D
-                                   : (is_k ? karena + ((size_t)(head - e.Hq) * mseq + pos) * e.D
-                                           : karena + ((size_t)(e.Hkv + head - e.Hq - e.Hkv) * mseq + pos) * e.D);
+                // element offset of this row's head inside the arena [L][2][Hkv][max_seq][D] (K heads, then V heads)
+                const size_t kvoff = (size_t)e.layer * 2 * e.Hkv * mseq * e.D +
+                                     ((size_t)(head - e.Hq) * mseq + pos) * e.D;      // head - Hq in [0, 2*Hkv)
+                const bool kv8 = !is_q && e.tab.kv_fp8;
+                H *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D : (H *)e.tab.kv_base[strm] + kvoff;
+                unsigned char *dst8 = (unsigned char *)e.tab.kv_base[strm] + kvoff;
+                const float inv_sc = kv8 ? 1.0f / e.tab.kv_scale[strm][(size_t)e.layer * 2 * e.Hkv + (head - e.Hq)] : 1.0f;
                 float x[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) x[c] = rnd<H>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
@@ -184,15 +216,17 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                         const int d = (within >> 1) + pr;
                         const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
                         const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
-                        dst[d] = (H)(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn));
-                        dst[d + hd] = (H)(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
+                        const float o0 = rnd<H>(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn)), o1 = rnd<H>(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
+                        if (kv8) { dst8[d] = to_fp8(o0, inv_sc); dst8[d + hd] = to_fp8(o1, inv_sc); }
+                        else { dst[d] = (H)o0; dst[d + hd] = (H)o1; }
                     }
                 } else {
                     if (EPI == EPI_QKV_PLAIN && is_q) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) x[c] = rnd<H>(x[c] * e.q_scale);
                     }
-                    store4(dst + within, x[0], x[1], x[2], x[3]);
+                    if (kv8) store4_fp8(dst8 + within, x[0], x[1], x[2], x[3], inv_sc);
+                    else store4(dst + within, x[0], x[1], x[2], x[3]);
                 }
             }
         }
@@ -717,6 +751,14 @@ __global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_
         q[d + hd] = from_f<T>(o1);
     } else {
         const int kvh = is_k ? head - Hq : head - Hq - Hkv;
+        if (tab.kv_fp8) {
+            unsigned char *dst8 = (unsigned char *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D +
+                                  ((size_t)(head - Hq) * max_seq + pos) * D;
+            const float inv_sc = 1.0f / tab.kv_scale[strm][(size_t)layer * 2 * Hkv + (head - Hq)];
+            dst8[d] = to_fp8(o0, inv_sc);
+            dst8[d + hd] = to_fp8(o1, inv_sc);
+            return;
+        }
         T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + pos) * D;
         dst[d] = from_f<T>(o0);
         dst[d + hd] = from_f<T>(o1);
@@ -776,10 +818,13 @@ __device__ long long g_att_stamps[16];
 #else
 #define ATT_STAMP(i) do { } while (0)
 #endif
-template <typename T, int D>
+// KV8: the arena holds fp8 e4m3 (tab.kv_fp8; 16-bit T and D >= 32 only): keys / values are widened to T in registers
+// (exact), the K scale multiplies the scores and the V scale the output.
+template <typename T, int D, bool KV8 = false>
 __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
                                                   T *__restrict__ out, int Hq, int Hkv, int arch,
                                                   float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
+    static_assert(!KV8 || (sizeof(T) == 2 && D >= 32), "fp8 KV needs a 16-bit model type and the MFMA score path");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     constexpr int ATT_RG = 256 / (D / 8);                         // key groups of the P.V phase, each leaves a partial sum
@@ -792,6 +837,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     const int pos0 = tab.grp_pos[blockIdx.y] - r0;
     const int kvh = head / (Hq / Hkv);
     const T *karena = (const T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
+    const unsigned char *karena8 = (const unsigned char *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
+    float k_scale = 1.f, v_scale = 1.f;
+    if constexpr (KV8) {
+        k_scale = tab.kv_scale[strm][(size_t)layer * 2 * Hkv + kvh];
+        v_scale = tab.kv_scale[strm][(size_t)layer * 2 * Hkv + Hkv + kvh];
+    }
     const int tid = threadIdx.x;
     ATT_STAMP(0);
     // long contexts (nsplit > 1, "flash-decoding"): workgroup z takes keys [kb, kb + s_hi) of the group's visible keys and
@@ -804,6 +855,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     const int vis0 = pos0 + r0 - kb;                              // local index of the last key row t = 0 may see
     const T *K = karena + ((size_t)kvh * max_seq + kb) * D;
     const T *Vv = karena + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
+    const unsigned char *K8 = karena8 + ((size_t)kvh * max_seq + kb) * D;
+    const unsigned char *V8 = karena8 + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
     __shared__ float ml[ATT_TQ][2];
 
     // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
@@ -817,9 +870,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int j = 0; j < VPF; ++j) {
             const int s2 = sg + j * NGRP_;
             if (s2 < s_hi) {
-                const u32x4 *src = reinterpret_cast<const u32x4 *>(Vv + (size_t)s2 * D + dp * 8);
-                vpre[j][0] = src[0];
-                if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
+                if constexpr (KV8) {
+                    vpre[j][0] = fp8x8_to_16<T>(*reinterpret_cast<const uint2 *>(V8 + (size_t)s2 * D + dp * 8));
+                } else {
+                    const u32x4 *src = reinterpret_cast<const u32x4 *>(Vv + (size_t)s2 * D + dp * 8);
+                    vpre[j][0] = src[0];
+                    if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
+                }
             }
         }
     };
@@ -851,9 +908,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
             for (int u = 0; u < 4; ++u) {
                 const int kt = kt0 + 4 * u;
                 if (kt * 16 < s_hi) {
-                    const T *kr = K + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
+                    if constexpr (KV8) {
+                        const unsigned char *kr8 = K8 + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
 #pragma unroll
-                    for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
+                        for (int dk = 0; dk < D / 32; ++dk)
+                            kf[u][dk] = fp8x8_to_16<T>(*reinterpret_cast<const uint2 *>(kr8 + dk * 32));
+                    } else {
+                        const T *kr = K + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
+#pragma unroll
+                        for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
+                    }
                 }
             }
             if (!v_issued) { issue_v(); v_issued = true; }
@@ -870,7 +934,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                     for (int j = 0; j < 4; ++j) {
                         const int s = kt * 16 + (lane >> 4) * 4 + j;
                         if (s < s_hi) {
-                            float v = rnd<T>(acc[j]);
+                            float v = rnd<T>(KV8 ? acc[j] * k_scale : acc[j]);
                             if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
                             sc[(size_t)mrow * s_cap + s] = (s <= vis0 + mrow) ? v : -INFINITY;
                         }
@@ -1044,7 +1108,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
 #pragma unroll 4
             for (int s = sg + VPF * NGRP; s < s_hi; s += NGRP) {
                 float v[8];
-                load8(Vv + (size_t)s * D + dp * 8, v);
+                if constexpr (KV8) {
+                    const u32x4 vr[1] = {fp8x8_to_16<T>(*reinterpret_cast<const uint2 *>(V8 + (size_t)s * D + dp * 8))};
+                    unpack8<T>(vr, v);
+                } else {
+                    load8(Vv + (size_t)s * D + dp * 8, v);
+                }
 #pragma unroll
                 for (int t = 0; t < NR; ++t) {
                     const float p = sc[(size_t)t * s_cap + s];
@@ -1074,7 +1143,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
             float a = 0.f;
 #pragma unroll
             for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
-            pz[(size_t)t * (D + 2) + d] = a;
+            pz[(size_t)t * (D + 2) + d] = KV8 ? a * v_scale : a;
         }
         if (tid < nr) { pz[(size_t)tid * (D + 2) + D] = ml[tid][0]; pz[(size_t)tid * (D + 2) + D + 1] = ml[tid][1]; }
         return;
@@ -1084,7 +1153,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         float a = 0.f;
 #pragma unroll
         for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
-        out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(a);
+        out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(KV8 ? a * v_scale : a);
     }
     ATT_STAMP(7);
 }

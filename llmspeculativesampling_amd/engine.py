@@ -70,6 +70,8 @@ class SpecDecModel:
         self.dtype = dtype
         self.device = torch.device(device)
         self.max_pos = int(max_pos or cfg.max_position_embeddings)
+        self.kv_dtype = None                         # None: KV arenas in the model dtype; "fp8": OCP e4m3 (config 5)
+        self.tp_group = None                         # tp.TPGroup when this model is one shard of a tensor-parallel target
         self._keep: List[torch.Tensor] = []          # owns every device tensor the handle points into
         self._arrays = []
         self.weight_bytes = 0                        # bytes the forward streams (embedding tables excluded)
@@ -218,7 +220,8 @@ class SpecDecModel:
 
     @classmethod
     def synthetic(cls, cfg: ModelConfig, seed: int, dtype=torch.bfloat16, device="cuda", max_pos=None,
-                  method: str = "torch", gain: float = 1.0, head_gain: float = 4.0, transform=None) -> "SpecDecModel":
+                  method: str = "torch", gain: float = 1.0, head_gain: float = 4.0, transform=None,
+                  seed_of=None) -> "SpecDecModel":
         """Random-init weights generated tensor by tensor (never the whole model at once on the host).
         ``transform(name, tensor) -> tensor`` post-processes each generated tensor (synth.acceptance_dial_pair)."""
         from .synth import param_shapes, _scale
@@ -233,7 +236,7 @@ class SpecDecModel:
                 rng = np.random.default_rng([int(seed), idx])
                 a = rng.standard_normal(size=shape, dtype=np.float32) * np.float32(std) + np.float32(mean)
                 return torch.from_numpy(a)
-            gen.manual_seed(int(seed) * 100003 + idx)
+            gen.manual_seed((int(seed_of(name)) if seed_of is not None else int(seed)) * 100003 + idx)
             t = torch.empty(shape, dtype=dtype, device=device)
             return t.normal_(mean, std, generator=gen)
 
@@ -244,23 +247,32 @@ class SpecDecModel:
         m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
         return m
 
-    def new_session(self, max_seq: int, max_rows: int = MAX_PREFILL_ROWS) -> "Session":
-        return Session(self, max_seq, max_rows)
+    def new_session(self, max_seq: int, max_rows: int = MAX_PREFILL_ROWS, kv_dtype: Optional[str] = None) -> "Session":
+        ses = Session(self, max_seq, max_rows, kv_dtype=kv_dtype or self.kv_dtype)
+        if self.tp_group is not None:
+            self.tp_group.bind(ses)
+        return ses
 
 
 class Session:
     """KV arena [L][2][H_kv][max_seq][D] + scratch for one sequence; ``cache_len`` is the number of
     positions held, so rollback is an assignment (reference kvcache_model.py:359-436)."""
 
-    def __init__(self, model: SpecDecModel, max_seq: int, max_rows: int = MAX_PREFILL_ROWS):
+    def __init__(self, model: SpecDecModel, max_seq: int, max_rows: int = MAX_PREFILL_ROWS, kv_dtype: Optional[str] = None):
         cfg = model.cfg
         self.model = model
         self.max_seq = int(min(max_seq, model.max_pos))
         self.max_rows = int(min(max_rows, MAX_PREFILL_ROWS, lib.sd_model_max_rows(model.handle)))
         dev = model.device
-        self.kv = torch.zeros((cfg.num_hidden_layers, 2, cfg.num_key_value_heads, self.max_seq, cfg.head_dim),
-                              dtype=model.dtype, device=dev)
-        assert self.kv.numel() * self.kv.element_size() == lib.sd_session_kv_bytes(model.handle, self.max_seq)
+        self.kv_fp8 = kv_dtype == "fp8"
+        assert kv_dtype in (None, "fp8"), kv_dtype
+        shape = (cfg.num_hidden_layers, 2, cfg.num_key_value_heads, self.max_seq, cfg.head_dim)
+        if self.kv_fp8:                              # 1 byte per element; x is stored as fp8(x / scale[layer, k|v, head])
+            self.kv = torch.zeros(shape, dtype=torch.uint8, device=dev)
+            self.kv_scale = torch.ones((cfg.num_hidden_layers, 2, cfg.num_key_value_heads), dtype=torch.float32, device=dev)
+        else:
+            self.kv = torch.zeros(shape, dtype=model.dtype, device=dev)
+            assert self.kv.numel() * self.kv.element_size() == lib.sd_session_kv_bytes(model.handle, self.max_seq)
         nbytes = lib.sd_session_scratch_bytes(model.handle, self.max_rows)
         self.scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.logits = torch.empty((min(self.max_rows, MAX_ROWS_PER_FORWARD), cfg.vocab_size), dtype=torch.float32,
@@ -270,6 +282,8 @@ class Session:
                                     self.scratch.data_ptr(), C.byref(h)), "sd_session_create")
         self.handle = h
         self.cache_len = 0
+        if self.kv_fp8:
+            check(lib.sd_session_set_kv_fp8(h, self.kv_scale.data_ptr()), "sd_session_set_kv_fp8")
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -312,6 +326,10 @@ class Session:
     def past_key_values(self):
         """The reference's tuple layout: one (k, v) pair of (1, H_kv, S, D) views per layer."""
         S = self.cache_len
+        if self.kv_fp8:                              # widened copies (the arena itself stays fp8)
+            kv = self.kv.view(torch.float8_e4m3fn)[:, :, :, :S, :].to(self.model.dtype) * \
+                self.kv_scale[:, :, :, None, None].to(self.model.dtype)
+            return [(kv[l, 0].unsqueeze(0), kv[l, 1].unsqueeze(0)) for l in range(kv.shape[0])]
         return [(self.kv[l, 0, :, :S, :].unsqueeze(0), self.kv[l, 1, :, :S, :].unsqueeze(0))
                 for l in range(self.kv.shape[0])]
 

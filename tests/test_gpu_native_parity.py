@@ -584,3 +584,124 @@ def test_fp16_speculative_pair_and_hf_module(hip):
     mod = transformers.LlamaForCausalLM(lc).eval().half()
     sm = hip.engine.as_specdec_model(mod)
     assert sm.dtype == torch.float16 and sm.new_session(16).kv.dtype == torch.float16
+
+
+# --------------------------------------------------------------------------- config 5: tensor-parallel target, fp8 KV
+TP_CFG = dict(arch="llama", vocab_size=1024, hidden_size=256, intermediate_size=704, num_hidden_layers=3,
+              num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256, rms_norm_eps=1e-5)
+
+
+def _run_ranks(fns):
+    """Run one callable per tensor-parallel rank, each on its own host thread and HIP stream (the loopback group's
+    all-reduce rendezvous needs all ranks in flight at once)."""
+    import threading
+    out, errs = [None] * len(fns), []
+
+    def work(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[r] = fns[r]()
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            errs.append((r, repr(e)))
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(len(fns))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs and all(not t.is_alive() for t in ts), errs
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_tensor_parallel_shards_vs_unsharded_forward(hip, dtype):
+    """Two Megatron shards of a GQA Llama (2 of 4 query heads, 1 of 2 KV heads, half of the MLP each) on one GPU through
+    the loopback group (same kernels and the same tp_reduce as the RCCL path; the all-reduce is an in-process
+    rendezvous): logits of both ranks are bit-identical to each other and equal the unsharded engine / the oracle within
+    the dtype's bound; each rank's KV arena holds its own KV head."""
+    from llmspeculativesampling_amd import tp
+    cfg = ModelConfig(**TP_CFG)
+    sd = make_state_dict(cfg, 70, dtype=dtype)
+    full = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    groups = tp.TPGroup.loopback(2)
+    shards = [tp.shard_model(cfg, sd, r, 2, group=groups[r], dtype=dtype) for r in range(2)]
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 40))).to(torch.int32).cuda()[0]
+    ref_ses = full.new_session(64)
+    sess = [m.new_session(64) for m in shards]
+    om = oracle.RefCausalLM(cfg, sd)
+    past, pos = None, 0
+    for q in (30, 1, 5, 4):
+        want_full = ref_ses.forward(ids[pos:pos + q], min(q, 5)).clone()
+        got = _run_ranks([lambda r=r: sess[r].forward(ids[pos:pos + q], min(q, 5)).clone() for r in range(2)])
+        o = om(ids[None, pos:pos + q].long().cpu(), past_key_values=past)
+        past = o.past_key_values
+        want = o.logits.float()[0, -min(q, 5):]
+        assert torch.equal(got[0], got[1])                       # every rank sees the same all-reduced sums
+        scale = float(want.abs().max())
+        tol = 1e-3 if dtype == torch.float32 else 0.04 * scale
+        assert float((got[0].cpu() - want).abs().max()) <= tol, (q, float((got[0].cpu() - want).abs().max()))
+        assert float((got[0] - want_full).abs().max()) <= tol
+        pos += q
+    for r in range(2):                                            # rank r's arena = KV head r of the full model
+        assert tuple(sess[r].kv.shape) == (3, 2, 1, 64, 64)
+        ktol = 1e-4 if dtype == torch.float32 else 0.05
+        ref = ref_ses.kv[:, :, r:r + 1, :pos].float()
+        assert float((sess[r].kv[:, :, :, :pos].float() - ref).abs().max()) <= ktol * max(1.0, float(ref.abs().max()))
+
+
+def test_tensor_parallel_target_in_speculative_sampling(hip):
+    """The whole decode loop with a 2-way tensor-parallel target (fp32, loopback group): every rank runs the same
+    speculative_sampling call on its shard with the same device-RNG seed and ends with the tokens of the unsharded run."""
+    from llmspeculativesampling_amd import tp
+    cfg = ModelConfig(**TP_CFG)
+    dcfg = load_config("tiny-llama-draft") if False else cfg
+    dsd = make_state_dict(cfg, 70)
+    tsd = perturb_state_dict(dsd, 71, 0.1)
+    draft = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32)
+    full = hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.float32)
+    prompt = torch.from_numpy(np.random.default_rng(8).integers(3, cfg.vocab_size, size=(1, 12))).cuda()
+    kw = dict(gamma=4, top_k=20, top_p=0.9)
+    want, wd = hip.S.speculative_sampling(prompt, draft, full, -1, None, 24, details=True, rng=hip.noise.DeviceNoise(31), **kw)
+    groups = tp.TPGroup.loopback(2)
+    shards = [tp.shard_model(cfg, tsd, r, 2, group=groups[r], dtype=torch.float32) for r in range(2)]
+    drafts = [hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.float32) for _ in range(2)]
+    res = _run_ranks([lambda r=r: hip.S.speculative_sampling(prompt, drafts[r], shards[r], -1, None, 24, details=True,
+                                                              rng=hip.noise.DeviceNoise(31), **kw) for r in range(2)])
+    for out, d in res:
+        assert torch.equal(out, want) and d["acc_len"] == wd["acc_len"]
+    assert 0 < sum(wd["acc_len"]) < 4 * len(wd["acc_len"])
+
+
+@pytest.mark.parametrize("name", ["llama_d128", "llama_d64_gqa"])
+def test_fp8_kv_arena_vs_16bit_arena(hip, name):
+    """fp8 (OCP e4m3) KV arena: K / V rows quantised where they are appended, widened in the attention kernel.  Same bf16
+    model with a bf16 arena and with an fp8 arena over a 150-token prompt + verify-sized steps: the arena is half the
+    bytes, its rows equal the bf16 ones within e4m3's 2^-4 relative step, and the logits stay within 6 % of the logit
+    scale (measured ~2 %) of the bf16-KV run and of the oracle."""
+    from test_gpu_parity import MID_CFGS
+    cfg = ModelConfig(**MID_CFGS[name])
+    sd = make_state_dict(cfg, 77, dtype=torch.bfloat16)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.bfloat16)
+    a, b = m.new_session(256), m.new_session(256, kv_dtype="fp8")
+    assert b.kv.dtype == torch.uint8 and b.kv.numel() * 2 == a.kv.numel() * a.kv.element_size()
+    ids = torch.from_numpy(np.random.default_rng(9).integers(3, cfg.vocab_size, size=(1, 167))).to(torch.int32).cuda()[0]
+    om = oracle.RefCausalLM(cfg, sd)
+    past, pos = None, 0
+    worst = 0.0
+    for q in (150, 1, 5, 9):
+        la = a.forward(ids[pos:pos + q], min(q, 9)).clone()
+        lb = b.forward(ids[pos:pos + q], min(q, 9)).clone()
+        o = om(ids[None, pos:pos + q].long().cpu(), past_key_values=past)
+        past = o.past_key_values
+        want = o.logits.float()[0, -min(q, 9):]
+        scale = float(want.abs().max())
+        worst = max(worst, float((lb - la).abs().max()) / scale)
+        assert float((lb - la).abs().max()) <= 0.06 * scale, (q, float((lb - la).abs().max()), scale)
+        assert float((lb.cpu() - want).abs().max()) <= 0.08 * scale
+        pos += q
+    print(f"{name}: fp8-KV logits within {worst:.3%} of the logit scale of the bf16-KV run")
+    ka, kb = a.past_key_values(), b.past_key_values()
+    for l in range(cfg.num_hidden_layers):
+        for x16, x8 in zip(ka[l], kb[l]):
+            err = (x8.float() - x16.float()).abs()
+            assert bool((err <= 0.0625 * x16.float().abs() + 2e-3).all())
