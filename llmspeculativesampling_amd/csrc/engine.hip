@@ -550,7 +550,9 @@ extern "C" int sd_tp_destroy(sd_tp *t) {
 
 extern "C" int sd_session_set_tp(sd_session *s, sd_tp *t) {
     SD_REQUIRE(s, "sd_session_set_tp: null session");
-    s->tp = (t && t->world > 1) ? t : nullptr;
+    // a group of one has nothing to reduce; SD_TP_FORCE=1 keeps it anyway (tests: the RCCL plumbing on a one-GPU box)
+    const char *force = getenv("SD_TP_FORCE");
+    s->tp = (t && (t->world > 1 || (force && atoi(force)))) ? t : nullptr;
     return SD_OK;
 }
 

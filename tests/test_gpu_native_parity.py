@@ -700,8 +700,30 @@ def test_fp8_kv_arena_vs_16bit_arena(hip, name):
         assert float((lb.cpu() - want).abs().max()) <= 0.08 * scale
         pos += q
     print(f"{name}: fp8-KV logits within {worst:.3%} of the logit scale of the bf16-KV run")
-    ka, kb = a.past_key_values(), b.past_key_values()
-    for l in range(cfg.num_hidden_layers):
-        for x16, x8 in zip(ka[l], kb[l]):
-            err = (x8.float() - x16.float()).abs()
-            assert bool((err <= 0.0625 * x16.float().abs() + 2e-3).all())
+    # layer 0's K / V depend only on the embeddings: there the two arenas hold the same values up to e4m3's rounding
+    # (3 mantissa bits: at most 2^-4 relative; deeper layers also see the quantised attention of the layers below)
+    for x16, x8 in zip(a.past_key_values()[0], b.past_key_values()[0]):
+        err = (x8.float() - x16.float()).abs()
+        assert bool((err <= 0.0625 * x16.float().abs() + 2e-3).all())
+
+
+def test_rccl_group_of_one_runs_the_all_reduce_path(hip):
+    """The RCCL side of tp_reduce on the one-GPU box: a communicator of world size 1 created from a unique id through the
+    C ABI (RCCL resolved with dlopen), kept on the session with SD_TP_FORCE=1, so every O / down projection goes through
+    fold + ncclAllReduce (an identity here): logits must equal the plain forward's."""
+    from llmspeculativesampling_amd import tp
+    cfg = ModelConfig(**TP_CFG)
+    sd = make_state_dict(cfg, 70, dtype=torch.bfloat16)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.bfloat16)
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 24))).to(torch.int32).cuda()[0]
+    want = m.new_session(32).forward(ids, 5).clone()
+    grp = tp.TPGroup.rccl(0, 1, lambda b: b)
+    os.environ["SD_TP_FORCE"] = "1"
+    try:
+        ses = m.new_session(32)
+        grp.bind(ses)
+        got = ses.forward(ids, 5).clone()
+    finally:
+        os.environ.pop("SD_TP_FORCE", None)
+    torch.cuda.synchronize()
+    assert float((got - want).abs().max()) <= 0.04 * float(want.abs().max())
