@@ -294,6 +294,18 @@ int sd_session_set_kv_fp8(sd_session *s, const float *scales);
 int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
                        float *logits_out, long ld_logits, void *stream);
 
+/* Tree verify (reference kvcache_model.py:38-136 forward_tree_attention with the extra attention
+ * mask of modeling_llama.py:684-689 / modeling_opt.py:660-667): ONE target forward over the n <= 64 nodes of a draft token
+ * tree.  tokens / positions / masks are DEVICE-side for tokens (int32[n]) and HOST-side for positions and masks:
+ * node i sits at position positions[i] (its depth; RoPE / learned position), attends to all `base_len` cached positions and
+ * to the nodes j with bit j of masks[i] set (its ancestors and itself, j <= i), and its K / V rows are appended at arena
+ * slot base_len + i.  Logits of all n nodes go to logits_out[n][vocab].  sd_session_compact_kv afterwards moves the kept
+ * path's rows together (reference kvcache_model.py:326-353 rollback_tree_attention): slot base_len + idx[j] -> base_len + j
+ * (idx: device int32[k], ascending) in every layer and head. */
+int sd_session_forward_tree(sd_session *s, const int32_t *tokens, const int32_t *positions, const uint64_t *masks, int n,
+                            int base_len, float *logits_out, long ld_logits, void *stream);
+int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream);
+
 /* Stream-batched forward: the new rows of up to 16 independent sequences share ONE pass over the
  * weights (same bytes streamed, n_items times the tokens).  Each item names its own session (KV arena), its token
  * buffer `seq` (device int32 indexed by ABSOLUTE position: the rows read seq[pos0 .. pos0+n_new)), its cache length

@@ -1120,7 +1120,7 @@ static void finish_table(RowTab &tab) {
     while (r < tab.n_rows) {
         int n = 1;
         while (r + n < tab.n_rows && n < ATT_TQ && tab.row_stream[r + n] == tab.row_stream[r] &&
-               tab.row_pos[r + n] == tab.row_pos[r] + n)
+               (tab.tree || tab.row_pos[r + n] == tab.row_pos[r] + n))     // tree rows group by storage order
             ++n;
         tab.grp_row0[tab.n_groups] = r;
         tab.grp_n[tab.n_groups] = n;
@@ -1178,6 +1178,74 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     for (int i = 0; i < n_logits; ++i) tab.xmap[i] = (unsigned char)(n_new - n_logits + i);   // n_new <= 256
     finish_table(tab);
     return run_forward(s, tab, pos0 + n_new, logits_out, ld_logits, stream);
+}
+
+// Tree verify (reference kvcache_model.py:38-136 forward_tree_attention + modeling_llama.py:684-689): the n rows are
+// the nodes of a draft token tree.  Node i has token tokens[i], position positions[i] (its depth: RoPE / learned
+// position), sees all `base_len` cached positions and the nodes whose bit is set in masks[i] (ancestors + itself, bit j
+// = node j, j <= i), and its K / V rows are appended at arena slot base_len + i.  Logits come out for all n nodes.
+extern "C" int sd_session_forward_tree(sd_session *s, const int32_t *tokens, const int32_t *positions, const uint64_t *masks,
+                                       int n, int base_len, float *logits_out, long ld_logits, void *stream) {
+    SD_REQUIRE(s && tokens && positions && masks && logits_out, "sd_session_forward_tree: null argument");
+    SD_REQUIRE(n >= 1 && n <= SD_MAX_ROWS && base_len >= 0, "sd_session_forward_tree: 1..%d nodes", SD_MAX_ROWS);
+    if (n > s->max_rows || base_len + n > s->max_seq) {
+        sd_set_error("sd_session_forward_tree: %d nodes after %d positions exceed max_rows %d / max_seq %d", n, base_len,
+                     s->max_rows, s->max_seq);
+        return SD_ERR_CAPACITY;
+    }
+    RowTab tab = {};
+    tab.n_rows = n;
+    tab.n_streams = 1;
+    tab.n_logit_rows = n;
+    tab.tree = 1;
+    tab.tree_base = base_len;
+    tab.kv_base[0] = s->kv;
+    tab.max_seq[0] = s->max_seq;
+    tab.kv_fp8 = s->kv_fp8;
+    tab.kv_scale[0] = s->kv_scale;
+    tab.tok_base[0] = tokens;                    // tree rows: the token of node i is tokens[i] (tab_tok)
+    for (int i = 0; i < n; ++i) {
+        SD_REQUIRE(positions[i] >= 0 && positions[i] < s->m->cfg.max_pos, "sd_session_forward_tree: position %d out of range", positions[i]);
+        SD_REQUIRE((masks[i] >> i) & 1ull, "sd_session_forward_tree: node %d must see itself", i);
+        SD_REQUIRE(i == 63 || (masks[i] >> (i + 1)) == 0, "sd_session_forward_tree: node %d sees a later node", i);
+        tab.row_pos[i] = positions[i];
+        tab.row_stream[i] = 0;
+        tab.tree_mask[i] = masks[i];
+        tab.xmap[i] = (unsigned char)i;
+    }
+    finish_table(tab);
+    return run_forward(s, tab, base_len + n, logits_out, ld_logits, stream);
+}
+
+// Gather-compaction of the KV arena after a tree verify (reference kvcache_model.py:326-353 rollback_tree_attention,
+// one kept path): the rows at slots base + idx[j] (idx ascending, j < k) move to base + j in every layer / head.
+__global__ void kv_compact_kernel(char *kv, int max_seq, int row_bytes, int base, const int *__restrict__ idx, int k) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    char *arena = kv + (size_t)blockIdx.x * max_seq * row_bytes;       // one (layer, k|v, head) plane per workgroup
+    const int n16 = row_bytes / 16;
+    for (int i = threadIdx.x; i < k * n16; i += blockDim.x) {
+        const int j = i / n16, c = i - j * n16;
+        reinterpret_cast<uint4 *>(sm)[i] = reinterpret_cast<const uint4 *>(arena + (size_t)(base + idx[j]) * row_bytes)[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < k * n16; i += blockDim.x) {
+        const int j = i / n16, c = i - j * n16;
+        reinterpret_cast<uint4 *>(arena + (size_t)(base + j) * row_bytes)[c] = reinterpret_cast<const uint4 *>(sm)[i];
+    }
+}
+
+extern "C" int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream) {
+    SD_REQUIRE(s && idx_dev && k >= 0 && k <= SD_MAX_ROWS && base_len >= 0 && base_len + k <= s->max_seq,
+               "sd_session_compact_kv: bad arguments");
+    if (k == 0) return SD_OK;
+    const sd_model_config &c = s->m->cfg;
+    const int row_bytes = c.head_dim * (s->kv_fp8 ? 1 : (int)esize(c.dtype));
+    SD_REQUIRE(row_bytes % 16 == 0, "sd_session_compact_kv: KV rows must be multiples of 16 bytes");
+    const int planes = c.n_layers * 2 * c.n_kv_heads;
+    hipLaunchKernelGGL(kv_compact_kernel, dim3(planes), dim3(256), (size_t)k * row_bytes, (hipStream_t)stream, s->kv, s->max_seq,
+                       row_bytes, base_len, idx_dev, k);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
 }
 
 // Stream-batched forward: the new rows of up to 16 independent sequences go through ONE pass

@@ -38,6 +38,12 @@ struct RowTab {
     const int32_t *tok_base[SD_MAX_STREAMS];        // stream's token buffer, indexed by absolute position
     void *kv_base[SD_MAX_STREAMS];                  // stream's KV arena [L][2][Hkv][max_seq][D]
     int max_seq[SD_MAX_STREAMS];                    // that arena's capacity
+    // tree verify (reference kvcache_model.py:38-136, forward_tree_attention): the rows are the nodes of a draft token
+    // tree appended after `tree_base` cached positions; row m sees every cached position and the tree rows whose bit
+    // is set in tree_mask[m] (its ancestors and itself).  row_pos[] then carries the RoPE / learned position of the
+    // node (its depth), while its K / V rows go to the arena slot tree_base + m.
+    int tree, tree_base;
+    unsigned long long tree_mask[SD_MAX_ROWS];
     int kv_fp8;                                     // the arenas hold OCP fp8 e4m3 (1 byte per element) instead of T
     const float *kv_scale[SD_MAX_STREAMS];          // fp8: per (layer, k|v, kv head) scales [L][2][Hkv], x = fp8 * scale
     // attention groups: <= ATT_TQ consecutive rows of one stream (first row, count, position of the first row, stream)
@@ -59,6 +65,12 @@ __device__ __forceinline__ size_t xoff(int m, int k, int K) {
 
 __device__ __forceinline__ int tab_pos(const RowTab &t, int m) { return t.contig ? t.pos0 + m : t.row_pos[m]; }
 __device__ __forceinline__ int tab_stream(const RowTab &t, int m) { return t.contig ? 0 : (int)t.row_stream[m]; }
+// token id of row m: read at its absolute position in the stream's token buffer, or (tree verify) at its node index
+__device__ __forceinline__ int tab_tok(const RowTab &t, int m, int pos) {
+    return t.tree ? t.tok_base[0][m] : t.tok_base[tab_stream(t, m)][pos];
+}
+// arena slot row m's K / V rows are written to: its position, or (tree verify) the next free slot
+__device__ __forceinline__ int tab_slot(const RowTab &t, int m) { return t.tree ? t.tree_base + m : tab_pos(t, m); }
 
 enum { NORM_RMS = 0, NORM_LN = 1 };
 enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual feeds the next GEMM / replaces x / no norm
@@ -202,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                 const int strm = tab_stream(e.tab, m), pos = tab_pos(e.tab, m), mseq = e.tab.max_seq[strm];
                 // element offset of this row's head inside the arena [L][2][Hkv][max_seq][D] (K heads, then V heads)
                 const size_t kvoff = (size_t)e.layer * 2 * e.Hkv * mseq * e.D +
-                                     ((size_t)(head - e.Hq) * mseq + pos) * e.D;      // head - Hq in [0, 2*Hkv)
+                                     ((size_t)(head - e.Hq) * mseq + tab_slot(e.tab, m)) * e.D;      // head - Hq in [0, 2*Hkv)
                 const bool kv8 = !is_q && e.tab.kv_fp8;
                 H *dst = is_q ? e.out + (size_t)m * e.Hq * e.D + head * e.D : (H *)e.tab.kv_base[strm] + kvoff;
                 unsigned char *dst8 = (unsigned char *)e.tab.kv_base[strm] + kvoff;
@@ -497,7 +509,7 @@ __global__ void embed_kernel(RowTab tab, const T *__restrict__ table, int dim, c
     const int pos = tab_pos(tab, row);
     // ids are validated on the host (IndexError, as nn.Embedding raises); the clamp only keeps a caller that goes
     // straight to the C ABI with a bad id from reading outside the table
-    const int tok = min(max(tab.tok_base[tab_stream(tab, row)][pos], 0), vocab - 1);
+    const int tok = min(max(tab_tok(tab, row, pos), 0), vocab - 1);
     const T *src = table + (size_t)tok * dim;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * dim : nullptr;
     for (int i = threadIdx.x; i < dim; i += blockDim.x) {
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(RowTab tab, const T *__
     float *red = xs + H;
     const int row = blockIdx.x;
     const int pos = tab_pos(tab, row);
-    const int tok = min(max(tab.tok_base[tab_stream(tab, row)][pos], 0), vocab - 1);   // see embed_kernel
+    const int tok = min(max(tab_tok(tab, row, pos), 0), vocab - 1);   // see embed_kernel
     const T *src = table + (size_t)tok * H;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * H : nullptr;
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
@@ -753,13 +765,13 @@ __global__ void qkv_epilogue_kernel(const float *__restrict__ part, int S, size_
         const int kvh = is_k ? head - Hq : head - Hq - Hkv;
         if (tab.kv_fp8) {
             unsigned char *dst8 = (unsigned char *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D +
-                                  ((size_t)(head - Hq) * max_seq + pos) * D;
+                                  ((size_t)(head - Hq) * max_seq + tab_slot(tab, row)) * D;
             const float inv_sc = 1.0f / tab.kv_scale[strm][(size_t)layer * 2 * Hkv + (head - Hq)];
             dst8[d] = to_fp8(o0, inv_sc);
             dst8[d + hd] = to_fp8(o1, inv_sc);
             return;
         }
-        T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + pos) * D;
+        T *dst = (is_k ? karena : varena) + ((size_t)kvh * max_seq + tab_slot(tab, row)) * D;
         dst[d] = from_f<T>(o0);
         dst[d + hd] = from_f<T>(o1);
     }
@@ -848,11 +860,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     // long contexts (nsplit > 1, "flash-decoding"): workgroup z takes keys [kb, kb + s_hi) of the group's visible keys and
     // leaves un-normalised partial sums (+ running max and denominator) for attn_combine_kernel; nsplit == 1 is the
     // whole range.  From here on key indices are local to the chunk.
-    const int s_all = pos0 + r0 + nr;                             // keys visible to the last row of the group
+    // tree verify: every row may see all tab.tree_base cached keys and, among the tree rows of this call, those in its
+    // mask; the causal arithmetic below then only bounds the key range (all tree rows), visibility comes from `vis`
+    const bool tree = tab.tree != 0;
+    const int s_all = tree ? tab.tree_base + tab.n_rows : pos0 + r0 + nr;   // keys visible to the last row of the group
     const int chunk = nsplit > 1 ? (((s_all + nsplit - 1) / nsplit + 15) & ~15) : s_all;
     const int kb = nsplit > 1 ? (int)blockIdx.z * chunk : 0;
     const int s_hi = max(0, min(s_all, kb + chunk) - kb);
     const int vis0 = pos0 + r0 - kb;                              // local index of the last key row t = 0 may see
+    auto vis = [&](int t, int s) -> bool {                        // may row t of the group see local key s?
+        if (!tree) return s <= vis0 + t;
+        const int g = s + kb - tab.tree_base;                     // index among the tree rows (< 0: a cached key)
+        return g < 0 || ((tab.tree_mask[min(r0 + t, SD_MAX_ROWS - 1)] >> g) & 1ull);
+    };
     const T *K = karena + ((size_t)kvh * max_seq + kb) * D;
     const T *Vv = karena + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
     const unsigned char *K8 = karena8 + ((size_t)kvh * max_seq + kb) * D;
@@ -936,7 +956,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                         if (s < s_hi) {
                             float v = rnd<T>(KV8 ? acc[j] * k_scale : acc[j]);
                             if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d);
-                            sc[(size_t)mrow * s_cap + s] = (s <= vis0 + mrow) ? v : -INFINITY;
+                            sc[(size_t)mrow * s_cap + s] = vis(mrow, s) ? v : -INFINITY;
                         }
                     }
                 }
@@ -971,7 +991,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         for (int t = 0; t < ATT_TQ; ++t) {
             float v = rnd<T>(acc[t]);                             // matmul result in T
             if (arch == SD_ARCH_LLAMA) v = rnd<T>(v * inv_sqrt_d) ;  // scale after the matmul (modeling_llama.py:346)
-            sc[(size_t)t * s_cap + s] = (s <= vis0 + t) ? v : -INFINITY;
+            sc[(size_t)t * s_cap + s] = vis(t, s) ? v : -INFINITY;
         }
     }
     ATT_STAMP(1);
@@ -990,7 +1010,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         const bool in_regs = s_hi <= SREG * LW;
         for (int t = grp; t < nr; t += ngrp) {
             float *row = sc + (size_t)t * s_cap;
-            const int len = max(0, min(s_hi, vis0 + t + 1));
+            const int len = tree ? s_hi : max(0, min(s_hi, vis0 + t + 1));
             float m, sum, lo, hi;
             if (in_regs) {
                 // one LDS read and one LDS write per score: the row stays in registers between the three passes.  Each

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, 
         const int H = p.H;
         for (int row = 0; row < M; ++row) {
             const int pos = tab_pos(e.tab, row);
-            const int tok = min(max(e.tab.tok_base[tab_stream(e.tab, row)][pos], 0), p.vocab - 1);
+            const int tok = min(max(tab_tok(e.tab, row, pos), 0), p.vocab - 1);
             const bf16_t *src = p.embed + (size_t)tok * H;
             const bf16_t *ps = p.pos_embed ? p.pos_embed + (size_t)(pos + p.pos_off) * H : nullptr;
             float v[8];

@@ -318,15 +318,80 @@ class KVCacheModel:
             ses.rollback(end_pos)
         self._hist_len = min(self._hist_len, end_pos)
 
-    # -- out-of-scope beam / tree methods keep their names --------
-    def forward_tree_attention(self, *a, **k):
-        raise NotImplementedError("tree attention (reference kvcache_model.py:38-136) is out of scope")
+    # -- tree attention ------------------------------------------------
+    @torch.no_grad()
+    def forward_tree_attention(self, input_ids: torch.Tensor, prefix: torch.Tensor, extra_attention_mask: torch.Tensor,
+                               position_ids: torch.Tensor, gather_pos: torch.Tensor) -> torch.Tensor:
+        """reference kvcache_model.py:38-136 for one input sequence (extra_sample_cnt == 1): the uncached prefix rows go
+        through the ordinary forward, then ONE tree forward (sd_session_forward_tree) scores every node of the draft
+        token tree: node i = input_ids[0, i] at position position_ids[0, i], visible keys = the whole prefix + the nodes
+        marked in extra_attention_mask[0, i, prefix_len:].  All new rows are normalised into the history; returns the
+        rows at gather_pos (slot -1 = the last prefix position; gather_pos[:, 1] is shifted in place, as there)."""
+        if input_ids.size(0) != 1 or prefix.size(0) != 1:
+            raise NotImplementedError("forward_tree_attention: one input sequence per call (extra_sample_cnt == 1)")
+        m = self._model
+        V, dev = m.cfg.vocab_size, m.device
+        P, N = int(prefix.size(-1)), int(input_ids.size(1))
+        if N > MAX_ROWS_PER_FORWARD:
+            raise ValueError(f"a tree of {N} nodes exceeds one verify pass ({MAX_ROWS_PER_FORWARD} rows)")
+        self._ensure(P + N + 1)
+        ses = self._session
+        cached = ses.cache_len
+        assert cached <= P
+        if cached < P:                                            # uncached prefix rows: ordinary causal forward
+            check_token_ids(prefix[0, cached:], V)
+            self._tok32[cached:P] = prefix[0, cached:].to(device=dev, dtype=torch.int32)
+            self.forward_rows(self._tok32, P, P - cached)
+            self.check_errors(cached, P)
+        check_token_ids(input_ids, V)
+        tree_tok = input_ids[0].to(device=dev, dtype=torch.int32).contiguous()
+        pos_host = (C.c_int32 * N)(*[int(x) for x in position_ids[0].tolist()])
+        em = extra_attention_mask[0, :, P:P + N].to("cpu")
+        bits = [int(sum(1 << j for j in range(N) if bool(em[i, j]))) for i in range(N)]
+        masks = (C.c_uint64 * N)(*bits)
+        logits = torch.empty((N, V), dtype=torch.float32, device=dev)
+        t0 = process_time_ns()
+        check(lib.sd_session_forward_tree(ses.handle, tree_tok.data_ptr(), pos_host, masks, N, P, logits.data_ptr(),
+                                          logits.stride(0), _stream()), "sd_session_forward_tree")
+        t1 = process_time_ns()
+        check(lib.sd_norm_probs(logits.data_ptr(), N, V, logits.stride(0), float(self._temperature), int(self._top_k or 0),
+                                float(self._top_p or 0.0), m.norm_mode, self._probs[P].data_ptr(), self._probs.stride(0),
+                                self._err[P].data_ptr(), self._norm_ws.data_ptr() if N <= ses.max_rows else None, _stream()),
+              "sd_norm_probs")
+        self.forward_time_dict["_model_time"] += t1 - t0
+        self.forward_time_dict["norm_prob_time"] += process_time_ns() - t1
+        ses.cache_len = P + N                                     # tree rows occupy arena slots P .. P+N-1
+        self._hist_len = P + N
+        self.check_errors(P, P + N)
+        gather_pos[:, 1] += P
+        return self._probs[gather_pos[:, 1].to(dev)].to(m.probs_dtype)
 
     def beam_rollback(self, *a, **k):
-        raise NotImplementedError("beam rollback (reference kvcache_model.py:312-324) is out of scope")
+        raise NotImplementedError("beam rollback (reference kvcache_model.py:312-324) serves beam_sample_with_kv_cache, "
+                                  "whose transformers 4.35 BeamSearchScorer dependency is not available (DESIGN.md 8)")
 
-    def rollback_tree_attention(self, *a, **k):
-        raise NotImplementedError("tree rollback (reference kvcache_model.py:326-353) is out of scope")
+    @torch.no_grad()
+    def rollback_tree_attention(self, input_idx: torch.Tensor, mask: torch.Tensor):
+        """reference kvcache_model.py:326-353 for one kept path: the cache and probability rows at the positions where
+        mask[0] is True (the prefix and the accepted nodes) are compacted to the front (sd_session_compact_kv gathers
+        the KV rows of every layer / head in one launch)."""
+        if input_idx.numel() != 1 or int(input_idx.reshape(-1)[0]) != 0:
+            raise NotImplementedError("rollback_tree_attention: one kept path of input 0 (extra_sample_cnt == 1)")
+        ses = self._session
+        keep = mask.reshape(mask.shape[-2] if mask.dim() > 1 else 1, -1)[0].to("cpu")
+        L = int(keep.numel())
+        assert L <= ses.cache_len
+        P = 0
+        while P < L and bool(keep[P]):                            # leading run of kept positions stays where it is
+            P += 1
+        idx = [i - P for i in range(P, L) if bool(keep[i])]
+        if idx:
+            idx_dev = torch.tensor(idx, dtype=torch.int32, device=self._model.device)
+            check(lib.sd_session_compact_kv(ses.handle, P, idx_dev.data_ptr(), len(idx), _stream()), "sd_session_compact_kv")
+            src = self._probs[P:L][idx_dev.long()].clone()
+            self._probs[P:P + len(idx)] = src
+        ses.cache_len = P + len(idx)
+        self._hist_len = P + len(idx)
 
     def beam_sample_with_kv_cache(self, *a, **k):
         raise NotImplementedError("beam sampling (reference kvcache_model.py:439-567) is out of scope")

@@ -94,3 +94,100 @@ def max_fn(x: torch.Tensor) -> torch.Tensor:
         dst = out if out.dim() == 1 else out[r]
         check(lib.sd_max_fn(src.data_ptr(), None, V, dst.data_ptr(), _mode(x), _stream()), "sd_max_fn")
     return out.to(x.dtype).reshape(x.shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Host-side helpers of the tree-attention variant.  Pure index / scalar arithmetic on a few
+# dozen numbers per iteration: they stay on the host, like in the reference.
+# ------------------------------------------------------------------------------------------------------------------
+def get_seq_att_mask(input_cnt, all_input_idx, all_beam_idx, all_next_token, input_len, pad_token_id, device="cpu"):
+    """reference utils.py:95-148.  Flattens the beam-sampled draft tree into per-input token rows: beam j of level l
+    appends all_next_token[l][j] to input all_input_idx[l][j] and attends to what its parent beam
+    (all_beam_idx[l][j], a beam of level l-1) attended to, plus itself.  Returns
+    (tokens (input_cnt, n), mask (input_cnt, n, input_len + n) with the prefix part all True, pos (input_cnt + nodes, 2)
+    = [input, slot] with leading [i, -1] rows, position_ids (input_cnt, n))."""
+    toks = [[] for _ in range(input_cnt)]
+    rows = [[] for _ in range(input_cnt)]
+    depth_of = [[] for _ in range(input_cnt)]
+    parent_masks = [[] for _ in range(all_input_idx[0].numel())]
+    pos = [[i, -1] for i in range(input_cnt)]
+    for level, (inps, beams, nxt) in enumerate(zip(all_input_idx, all_beam_idx, all_next_token)):
+        this_level = []
+        for j in range(inps.numel()):
+            i, b = int(inps[j]), int(beams[j])
+            slot = len(toks[i])
+            pos.append([i, slot])
+            toks[i].append(int(nxt[j]))
+            depth_of[i].append(input_len + level)
+            inherited = parent_masks[b]
+            m = inherited + [False] * (slot - len(inherited)) + [True]
+            rows[i].append(m)
+            this_level.append(m)
+        parent_masks = this_level
+    n = max(len(t) for t in toks)
+    mask = torch.zeros((input_cnt, n, input_len + n), dtype=torch.bool)
+    mask[:, :, :input_len] = True
+    seq = torch.full((input_cnt, n), int(pad_token_id), dtype=torch.long)
+    pids = torch.zeros((input_cnt, n), dtype=torch.long)
+    for i in range(input_cnt):
+        k = len(toks[i])
+        seq[i, :k] = torch.tensor(toks[i], dtype=torch.long)
+        pids[i, :k] = torch.tensor(depth_of[i], dtype=torch.long)
+        for r, m in enumerate(rows[i]):
+            mask[i, r, input_len:input_len + len(m)] = torch.tensor(m, dtype=torch.bool)
+    return seq.to(device), mask.to(device), torch.tensor(pos, dtype=torch.long, device=device), pids.to(device)
+
+
+def get_accept_prob(p, q):
+    """reference utils.py:247-250: sum_i min(1, p_i / (q_i + 1e-6)) * q_i."""
+    r = p / (q + 1e-6)
+    return torch.sum(torch.clamp(r, max=1.0) * q)
+
+
+def update_large_prob(p, q):
+    """reference utils.py:252-255: norm(max(p - q, 0)) with the +1e-6 denominator."""
+    d = torch.clamp(p - q, min=0.0)
+    return d / (d.sum() + 1e-6)
+
+
+def get_num_acc_prob(p, q, m):
+    """reference utils.py:316-337 (with :257-314): distribution of how many of m drafts drawn from q get accepted
+    against p when every rejection replaces p by its residual.  alpha_i is the acceptance probability after i
+    rejections; the count recursion is P(n, k) = sum_i alpha_i prod_{j<i}(1 - alpha_j) P(n - i, k - 1), restarting from
+    alpha_0 as the reference's does.  Returns (prob, expect); index quirk kept: prob[k - 1] = P(m, k), prob[m] = P(m, 0)."""
+    alpha = []
+    cur = p.clone()
+    for _ in range(m):
+        alpha.append(get_accept_prob(cur, q))
+        cur = update_large_prob(cur, q)
+    none = [1.0]                                     # none[i] = prod_{j<i} (1 - alpha_j)
+    for a in alpha:
+        none.append(none[-1] * (1 - a))
+    table = {}
+
+    def count(n, k):
+        if n < k:
+            return 0
+        if n == 0 and k == 0:
+            return 1
+        if k == 0:
+            return none[n]
+        if (n, k) not in table:
+            table[(n, k)] = sum(none[i - 1] * alpha[i - 1] * count(n - i, k - 1) for i in range(1, n + 1))
+        return table[(n, k)]
+    prob = torch.zeros(m + 1, dtype=torch.float32)
+    expect = 0.0
+    for k in range(m + 1):
+        v = count(m, k)
+        prob[k - 1] = v
+        expect = expect + v * k
+    return prob, expect
+
+
+def get_expect_cnt_by_thres(p_width, expect_thres):
+    """reference utils.py:339-350."""
+    n, mass = p_width.numel(), 0
+    while mass < expect_thres and n > 0:
+        n -= 1
+        mass += p_width[n]
+    return int(n)

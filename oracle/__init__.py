@@ -22,3 +22,4 @@ from .models_ref import RefCausalLM  # noqa: F401
 from .kvcache_ref import RefKVCacheModel  # noqa: F401
 from .specdec_ref import speculative_sampling, autoregressive_sampling  # noqa: F401
 from .multi_ref import multi_speculative_sampling  # noqa: F401
+from . import tree_ref  # noqa: F401

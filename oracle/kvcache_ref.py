@@ -63,6 +63,43 @@ class RefKVCacheModel:
         return self._prob_history[:, -1, :]
 
     @torch.no_grad()
+    def forward_tree_attention(self, input_ids, prefix, extra_attention_mask, position_ids, gather_pos):
+        """kvcache_model.py:38-136: one forward over the uncached prefix rows + the nodes of a draft token tree (extra
+        attention mask, per-node position ids); every new row is normalised and appended to the history; returns the rows
+        at gather_pos (row -1 of the tree = the last prefix position).  gather_pos is modified in place like there."""
+        P = prefix.size(-1)
+        if self._past_key_values is None:
+            if prefix.size(0) < input_ids.size(0):
+                prefix = prefix.repeat(input_ids.size(0), 1)
+            ids = torch.cat((prefix, input_ids), dim=1)
+            pos = torch.cat((torch.arange(P).view(1, -1).repeat(position_ids.size(0), 1), position_ids), dim=1)
+            out = self._model(ids, extra_attention_mask=extra_attention_mask, position_ids=pos)
+            self._prob_history = self._normalise_rows(out.logits)
+        else:
+            cached = self._past_key_values[0][0].shape[2]
+            ids = torch.cat((prefix, input_ids), dim=1)[:, cached:]
+            pos = torch.cat((torch.arange(P).view(1, -1).repeat(position_ids.size(0), 1), position_ids), dim=1)[:, cached:]
+            out = self._model(ids, past_key_values=self._past_key_values, use_cache=True,
+                              extra_attention_mask=extra_attention_mask, position_ids=pos)
+            self._prob_history = torch.cat([self._prob_history, self._normalise_rows(out.logits)], dim=1)
+        self._past_key_values = out.past_key_values
+        gather_pos[:, 1] += P
+        return self._prob_history[gather_pos[:, 0], gather_pos[:, 1]]
+
+    @torch.no_grad()
+    def rollback_tree_attention(self, input_idx, mask):
+        """kvcache_model.py:326-353: keep, for each of the `width` outputs, the cache rows of batch element input_idx[w]
+        at the positions where mask[w] is True (the prefix and the accepted path), compacted."""
+        width = input_idx.numel()
+        _, nh, _, d = self._past_key_values[0][0].size()
+
+        def pick(t):
+            return t[input_idx].transpose(1, 2)[mask].view(width, -1, nh, d).transpose(1, 2)
+        self._past_key_values = [(pick(k), pick(v)) for k, v in self._past_key_values]
+        V = self._prob_history.size(-1)
+        self._prob_history = self._prob_history[input_idx][mask].view(width, -1, V)
+
+    @torch.no_grad()
     def generate(self, input: torch.Tensor, gamma: int, multi: int = 1, strategy: str = "beam") -> torch.Tensor:
         x = input
         if strategy == "iid" and multi > 1:                               # (:273-274)

@@ -55,15 +55,32 @@ def _rot_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV]):
+def _tree_bias(bias, extra_attention_mask, dtype):
+    """Tree attention (modeling_llama.py:684-689, modeling_opt.py:660-667): finfo.min is ADDED to the causal bias of the
+    last extra_cnt query rows wherever the extra mask is False."""
+    if extra_attention_mask is None:
+        return bias
+    add = torch.where(extra_attention_mask, torch.zeros((), dtype=dtype), torch.full((), torch.finfo(dtype).min, dtype=dtype))
+    n = extra_attention_mask.size(1)
+    bias = bias.expand(extra_attention_mask.size(0), -1, -1, -1).clone()
+    bias[:, :, -n:, :] += add[:, None, :, :]
+    return bias
+
+
+def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV],
+                  extra_attention_mask=None, position_ids=None):
     dt = sd["model.embed_tokens.weight"].dtype
     H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     B, q_len = ids.shape          # B > 1 only for the width-w drafts of multi_speculative_sampling (oracle/multi_ref.py)
     n_past = past[0][0].shape[2] if past else 0
     x = F.embedding(ids, sd["model.embed_tokens.weight"])
-    cos, sin = _rope_tables(D, n_past + q_len, cfg.rope_theta, dt)
-    cos, sin = cos[n_past:n_past + q_len][None, None], sin[n_past:n_past + q_len][None, None]
-    bias = _causal_bias(q_len, n_past, dt)[None, None]
+    if position_ids is None:
+        cos, sin = _rope_tables(D, n_past + q_len, cfg.rope_theta, dt)
+        cos, sin = cos[n_past:n_past + q_len][None, None], sin[n_past:n_past + q_len][None, None]
+    else:                                            # tree nodes: the position is the node's depth (modeling_llama.py:180-188)
+        cos, sin = _rope_tables(D, int(position_ids.max()) + 1, cfg.rope_theta, dt)
+        cos, sin = cos[position_ids][:, None], sin[position_ids][:, None]
+    bias = _tree_bias(_causal_bias(q_len, n_past, dt)[None, None], extra_attention_mask, dt)
     new_past: KV = []
     for li in range(cfg.num_hidden_layers):
         p = f"model.layers.{li}."
@@ -96,7 +113,8 @@ def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Opt
 
 # --------------------------------------------------------------------------- OPT
 
-def opt_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV]):
+def opt_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV],
+                extra_attention_mask=None, position_ids=None):
     d = "model.decoder."
     dt = sd[d + "embed_tokens.weight"].dtype
     H, D, hid = cfg.num_attention_heads, cfg.head_dim, cfg.hidden_size
@@ -104,12 +122,12 @@ def opt_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optio
     n_past = past[0][0].shape[2] if past else 0
     x = F.embedding(ids, sd[d + "embed_tokens.weight"])
     # learned positions, offset 2 (modeling_opt.py:98-124); an all-ones mask makes them n_past..n_past+q-1
-    pos = torch.arange(n_past, n_past + q_len) + 2
-    pe = F.embedding(pos[None], sd[d + "embed_positions.weight"])
+    pos = (torch.arange(n_past, n_past + q_len)[None] if position_ids is None else position_ids) + 2
+    pe = F.embedding(pos, sd[d + "embed_positions.weight"])
     if d + "project_in.weight" in sd:
         x = F.linear(x, sd[d + "project_in.weight"])
     x = x + pe
-    bias = _causal_bias(q_len, n_past, dt)[None, None]
+    bias = _tree_bias(_causal_bias(q_len, n_past, dt)[None, None], extra_attention_mask, dt)
     pre = cfg.do_layer_norm_before
     eps = cfg.layer_norm_eps
     scaling = D ** -0.5
@@ -165,8 +183,8 @@ class RefCausalLM:
         self.n_calls = 0
 
     @torch.no_grad()
-    def __call__(self, input_ids, past_key_values=None, use_cache=True, **_):
+    def __call__(self, input_ids, past_key_values=None, use_cache=True, extra_attention_mask=None, position_ids=None, **_):
         fwd = llama_forward if self.cfg.arch == "llama" else opt_forward
-        logits, kv = fwd(self.cfg, self.sd, input_ids, past_key_values)
+        logits, kv = fwd(self.cfg, self.sd, input_ids, past_key_values, extra_attention_mask, position_ids)
         self.n_calls += 1
         return SimpleNamespace(logits=logits, past_key_values=kv)

@@ -448,6 +448,78 @@ def g8_lowprec():
           sum(c["tie_sensitive"] for c in cases["norm"]), "traces:", sum(c["tie_sensitive"] for c in cases["trace"]))
 
 
+def _tree_inputs(rng, V, widths, parents):
+    """A hand-made draft tree for get_seq_att_mask: level l has len(widths[l]) beams, beam j hangs below beam
+    parents[l][j] of the previous level (level 0 hangs below the prompt)."""
+    all_input_idx = [torch.zeros(len(w), dtype=torch.long) for w in widths]
+    all_beam_idx = [torch.tensor(pp, dtype=torch.long) for pp in parents]
+    all_next_token = [torch.from_numpy(rng.integers(3, V, size=len(w))) for w in widths]
+    return all_input_idx, all_beam_idx, all_next_token
+
+
+@torch.no_grad()
+def g9_tree():
+    """Tree attention: the reference's get_seq_att_mask, KVCacheModel.forward_tree_attention /
+    rollback_tree_attention on its own model classes (extra attention mask + per-node position ids), and the
+    acceptance-count recursion get_num_acc_prob / get_expect_cnt_by_thres."""
+    from oracle import tree_ref
+    cases, blobs = dict(tree=[], dp=[]), {}
+    shapes = [([0, 1, 2], [0, 0, 0]), ([0, 1, 2], [0, 0, 2]), ([0, 1, 2], [1, 2, 2])]
+    for ci, (cfg_name, seed) in enumerate([("tiny-llama-gqa", 61), ("tiny-llama-target", 62), ("tiny-opt-pre", 63), ("tiny-opt-post", 64)]):
+        cfg = load_config(cfg_name)
+        sd = make_state_dict(cfg, seed)
+        model = ref_model(cfg, sd)
+        rng = np.random.default_rng([9000, ci])
+        V, P = cfg.vocab_size, 7
+        prompt = torch.from_numpy(rng.integers(3, V, size=(1, P)))
+        ai, ab, at = _tree_inputs(rng, V, [w for w, _ in shapes], [pp for _, pp in shapes])
+        out_seq, mask, pos, pids = ref_utils.get_seq_att_mask(1, ai, ab, at, P, 0, device="cpu")
+        o2 = tree_ref.get_seq_att_mask(1, ai, ab, at, P, 0)
+        assert all(torch.equal(a, b) for a, b in zip((out_seq, mask, pos, pids), o2)), "oracle get_seq_att_mask != reference"
+        kv = ref_kv.KVCacheModel(model, 1, 20, 0.9)
+        p1 = kv.forward_tree_attention(out_seq, prompt, mask, pids, pos.clone())
+        okv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1, 20, 0.9)
+        op1 = okv.forward_tree_attention(out_seq, prompt, mask, pids, pos.clone())
+        assert float((op1 - p1).abs().max()) < 1e-5, "oracle forward_tree_attention != reference"
+        # accept the chain  level0 beam 0 -> level1 beam 1 -> level2 beam 0  (slots 0, 4, 6): the mask row of the leaf
+        leaf = 6
+        keep = mask[0, leaf][None].clone()
+        kv.rollback_tree_attention(torch.tensor([0]), keep)
+        okv.rollback_tree_attention(torch.tensor([0]), keep)
+        k_ref = kv._past_key_values[-1][0]
+        assert float((okv._past_key_values[-1][0] - k_ref).abs().max()) < 1e-5
+        path = [int(out_seq[0, s_]) for s_ in torch.nonzero(mask[0, leaf, P:]).flatten().tolist()]
+        # second round on the compacted cache: prompt + accepted path + one more token, a two-level tree
+        prefix2 = torch.cat([prompt, torch.tensor([path + [int(rng.integers(3, V))]])], dim=1)
+        P2 = prefix2.shape[1]
+        ai2, ab2, at2 = _tree_inputs(rng, V, [[0, 1], [0, 1]], [[0, 0], [1, 1]])
+        out2, mask2, pos2, pids2 = ref_utils.get_seq_att_mask(1, ai2, ab2, at2, P2, 0, device="cpu")
+        p2 = kv.forward_tree_attention(out2, prefix2, mask2, pids2, pos2.clone())
+        op2 = okv.forward_tree_attention(out2, prefix2, mask2, pids2, pos2.clone())
+        assert float((op2 - p2).abs().max()) < 1e-5
+        key = f"t{ci}"
+        for nm, t in (("prompt", prompt), ("tok", torch.stack(at)), ("beam", torch.stack(ab)), ("seq", out_seq), ("mask", mask),
+                      ("pos", pos), ("pids", pids), ("p1", p1), ("keep", keep), ("k_last", k_ref), ("hist", kv._prob_history[:, :P + 3]),
+                      ("prefix2", prefix2), ("tok2", torch.stack(at2)), ("beam2", torch.stack(ab2)), ("p2", p2)):
+            blobs[f"{key}_{nm}"] = t.detach().numpy()
+        cases["tree"].append(dict(id=key, cfg=cfg_name, seed=seed, P=P, leaf=leaf, top_k=20, top_p=0.9))
+    for di, (V, m, sg) in enumerate([(50, 2, 0.5), (50, 3, 1.0), (200, 4, 0.3), (200, 4, 2.0), (1000, 5, 0.7)]):
+        rng = np.random.default_rng([9100, di])
+        z = torch.from_numpy(rng.standard_normal(V, dtype=np.float32) * 2)
+        q = torch.softmax(z, 0)
+        p = torch.softmax(z + sg * torch.from_numpy(rng.standard_normal(V, dtype=np.float32)), 0)
+        prob, expect = ref_utils.get_num_acc_prob(p, q, m)
+        oprob, oexp = tree_ref.get_num_acc_prob(p, q, m)
+        assert torch.allclose(oprob, prob, atol=1e-6) and abs(float(oexp) - float(expect)) < 1e-5
+        cnts = [ref_utils.get_expect_cnt_by_thres(prob, th) for th in (0.3, 0.5, 0.7, 0.9)]
+        assert cnts == [tree_ref.get_expect_cnt_by_thres(prob, th) for th in (0.3, 0.5, 0.7, 0.9)]
+        blobs[f"d{di}_p"], blobs[f"d{di}_q"], blobs[f"d{di}_prob"] = p.numpy(), q.numpy(), prob.numpy()
+        cases["dp"].append(dict(id=f"d{di}", V=V, m=m, expect=float(expect), thres=[0.3, 0.5, 0.7, 0.9], counts=cnts))
+    np.savez_compressed(os.path.join(HERE, "g9_tree.npz"), **blobs)
+    json.dump(cases, open(os.path.join(HERE, "g9_tree.json"), "w"), indent=0)
+    print("G9:", {k: len(v) for k, v in cases.items()})
+
+
 def g5_traces():
     """End-to-end token traces of the reference's own model classes on tiny configs."""
     cases, blobs = [], {}
@@ -693,7 +765,7 @@ def misc():
 
 
 if __name__ == "__main__":
-    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi, g8=g8_lowprec)
+    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi, g8=g8_lowprec, g9=g9_tree)
     for name in (sys.argv[1:] or list(todo)):             # e.g. `make_golden.py g7` regenerates one fixture set
         todo[name]()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))

@@ -727,3 +727,69 @@ def test_rccl_group_of_one_runs_the_all_reduce_path(hip):
         os.environ.pop("SD_TP_FORCE", None)
     torch.cuda.synchronize()
     assert float((got - want).abs().max()) <= 0.04 * float(want.abs().max())
+
+
+# --------------------------------------------------------------------------- tree attention
+from golden_io import load as _load_golden                          # noqa: E402
+G9_META, G9 = _load_golden("g9_tree")
+
+
+@pytest.mark.parametrize("case", G9_META["tree"], ids=[c["id"] for c in G9_META["tree"]])
+def test_tree_attention_forward_and_rollback_golden(hip, case):
+    """KVCacheModel.forward_tree_attention / rollback_tree_attention through the HIP engine against the values the
+    reference produced with its own model classes (G9): one tree forward over 9 nodes (tree-mask attention: every node
+    sees the prefix and its ancestors; RoPE / learned position = depth; K/V appended at consecutive arena slots),
+    probabilities of all gathered nodes, then the KV gather-compaction of the accepted path and a second round on the
+    compacted cache.  fp32: probabilities within 1e-5, cache rows within 1e-4."""
+    key = case["id"]
+    cfg = load_config(case["cfg"])
+    sd = make_state_dict(cfg, case["seed"])
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=torch.float32)
+    P = case["P"]
+    prompt = torch.from_numpy(G9[key + "_prompt"]).cuda()
+    tok, beam = torch.from_numpy(G9[key + "_tok"]), torch.from_numpy(G9[key + "_beam"])
+    ai = [torch.zeros(tok.shape[1], dtype=torch.long) for _ in range(tok.shape[0])]
+    seq, mask, pos, pids = hip.S.get_seq_att_mask(1, ai, list(beam), list(tok), P, 0, device="cuda")
+    kv = hip.S.KVCacheModel(m, 1, case["top_k"], case["top_p"])
+    p1 = kv.forward_tree_attention(seq, prompt, mask, pids, pos.clone())
+    want = torch.from_numpy(G9[key + "_p1"])
+    assert torch.equal(p1.cpu() > 0, want > 0)
+    np.testing.assert_allclose(p1.cpu().numpy(), want.numpy(), atol=1e-5)
+    assert tuple(kv._prob_history.shape) == (1, P + seq.shape[1], cfg.vocab_size)
+    kv.rollback_tree_attention(torch.tensor([0]), torch.from_numpy(G9[key + "_keep"]))
+    k_last = kv._past_key_values[-1][0].cpu().numpy()
+    np.testing.assert_allclose(k_last, G9[key + "_k_last"], atol=1e-4)
+    np.testing.assert_allclose(kv._prob_history.cpu().numpy(), G9[key + "_hist"], atol=1e-5)
+    prefix2 = torch.from_numpy(G9[key + "_prefix2"]).cuda()
+    tok2, beam2 = torch.from_numpy(G9[key + "_tok2"]), torch.from_numpy(G9[key + "_beam2"])
+    ai2 = [torch.zeros(tok2.shape[1], dtype=torch.long) for _ in range(tok2.shape[0])]
+    seq2, mask2, pos2, pids2 = hip.S.get_seq_att_mask(1, ai2, list(beam2), list(tok2), prefix2.shape[1], 0, device="cuda")
+    p2 = kv.forward_tree_attention(seq2, prefix2, mask2, pids2, pos2.clone())
+    np.testing.assert_allclose(p2.cpu().numpy(), G9[key + "_p2"], atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,kv_dtype", [(torch.bfloat16, None), (torch.bfloat16, "fp8"), (torch.float16, None)],
+                         ids=["bf16", "bf16_fp8kv", "fp16"])
+def test_tree_attention_wide_tree_16bit_vs_oracle(hip, dtype, kv_dtype):
+    """A 40-node tree (5 levels x 8 beams, the shape of num_beams = 8, gamma = 4 plus the root level) on the MFMA
+    attention path, GQA, D = 64, after a 150-token prefix, in bf16 / fp16 and with the fp8 KV arena: node probabilities
+    against the oracle's tree forward in the same dtype (total variation <= 0.05 per node; 0.12 with fp8 KV)."""
+    from test_gpu_parity import MID_CFGS
+    cfg = ModelConfig(**MID_CFGS["llama_d64_gqa"])
+    sd = make_state_dict(cfg, 77, dtype=dtype, gain=0.7)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    m.kv_dtype = kv_dtype
+    rng = np.random.default_rng(12)
+    P, W, LV = 150, 8, 5
+    prompt = torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(1, P)))
+    ai = [torch.zeros(W, dtype=torch.long) for _ in range(LV)]
+    ab = [torch.from_numpy(rng.integers(0, W, size=W)) for _ in range(LV)]
+    at = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=W)) for _ in range(LV)]
+    seq, mask, pos, pids = hip.S.get_seq_att_mask(1, ai, ab, at, P, 0)
+    okv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1, 20, 0.9)
+    want = okv.forward_tree_attention(seq, prompt, mask, pids, pos.clone()).float()
+    kv = hip.S.KVCacheModel(m, 1, 20, 0.9)
+    got = kv.forward_tree_attention(seq.cuda(), prompt.cuda(), mask.cuda(), pids.cuda(), pos.clone().cuda()).float().cpu()
+    tv = 0.5 * (got - want).abs().sum(-1)
+    print(f"tree of {seq.shape[1]} nodes: max total variation {float(tv.max()):.4f}, mean {float(tv.mean()):.4f}")
+    assert float(tv.max()) <= (0.12 if kv_dtype else 0.05)

@@ -305,3 +305,36 @@ def test_shard_config_rejects_uneven_splits_and_non_llama():
         shard_config(c70, 16)                                       # 8 KV heads do not split over 16 ranks
     with pytest.raises(NotImplementedError):
         shard_config(load_config("opt-13b"), 2)
+
+
+# --------------------------------------------------------------------------- tree-attention host helpers (8(f) rank 4)
+def test_tree_helpers_match_reference_fixtures():
+    """The drop-in's get_seq_att_mask / get_num_acc_prob / get_expect_cnt_by_thres (host-side index and scalar
+    arithmetic, reference utils.py:95-148, 247-350) against the values recorded from the reference (G9)."""
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_io import load
+    import llmspeculativesampling_amd.sampling as S
+    meta, blobs = load("g9_tree")
+    for case in meta["tree"]:
+        key = case["id"]
+        for suffix, plen in (("", case["P"]), ("2", int(blobs[key + "_prefix2"].shape[1]))):
+            tok, beam = torch.from_numpy(blobs[f"{key}_tok{suffix}"]), torch.from_numpy(blobs[f"{key}_beam{suffix}"])
+            ai = [torch.zeros(tok.shape[1], dtype=torch.long) for _ in range(tok.shape[0])]
+            seq, mask, pos, pids = S.get_seq_att_mask(1, ai, list(beam), list(tok), plen, 0)
+            if suffix == "":
+                for got, nm in ((seq, "seq"), (mask, "mask"), (pos, "pos"), (pids, "pids")):
+                    np.testing.assert_array_equal(got.numpy(), blobs[f"{key}_{nm}"])
+            assert mask.shape == (1, seq.shape[1], plen + seq.shape[1]) and bool(mask[0, :, :plen].all())
+    for case in meta["dp"]:
+        p, q = torch.from_numpy(blobs[case["id"] + "_p"]), torch.from_numpy(blobs[case["id"] + "_q"])
+        prob, expect = S.get_num_acc_prob(p, q, case["m"])
+        np.testing.assert_allclose(prob.numpy(), blobs[case["id"] + "_prob"], atol=1e-6)
+        assert abs(float(expect) - case["expect"]) < 1e-5
+        assert [S.get_expect_cnt_by_thres(prob, th) for th in case["thres"]] == case["counts"]
+    # two inputs (extra_sample_cnt = 2): ragged rows are padded, the padding rows see nothing of the tree
+    ai = [torch.tensor([0, 1, 0]), torch.tensor([0, 1, 1])]
+    seq, mask, pos, pids = S.get_seq_att_mask(2, ai, [torch.tensor([0, 1, 0]), torch.tensor([0, 1, 2])],
+                                              [torch.tensor([5, 6, 7]), torch.tensor([8, 9, 10])], 4, 99)
+    assert seq.tolist() == [[5, 7, 8], [6, 9, 10]] and pos[:2].tolist() == [[0, -1], [1, -1]]
+    assert pids.tolist() == [[4, 4, 5], [4, 5, 5]]

@@ -291,3 +291,50 @@ def test_lowprec_accept_block_golden(case):
     np.testing.assert_array_equal(out.numpy()[0], G8[case["id"] + "_out"])
     assert d["acc_len"] == case["acc_len"] and d["target_call_times"] == case["target_call_times"]
     assert noise.exhausted()
+
+
+# --------------------------------------------------------------------------- G9: tree attention
+G9_META, G9 = load("g9_tree")
+TREE_SHAPES = [([0, 1, 2], [0, 0, 0]), ([0, 1, 2], [0, 0, 2]), ([0, 1, 2], [1, 2, 2])]
+
+
+def tree_inputs(blobs, key, suffix=""):
+    tok, beam = torch.from_numpy(blobs[f"{key}_tok{suffix}"]), torch.from_numpy(blobs[f"{key}_beam{suffix}"])
+    return [torch.zeros(tok.shape[1], dtype=torch.long) for _ in range(tok.shape[0])], list(beam), list(tok)
+
+
+@pytest.mark.parametrize("case", G9_META["tree"], ids=[c["id"] for c in G9_META["tree"]])
+def test_tree_attention_forward_and_rollback_golden(case):
+    """oracle get_seq_att_mask / forward_tree_attention / rollback_tree_attention against the reference's own run on its
+    model classes: mask + position ids, probabilities of every tree node, the compacted cache, a second round."""
+    from oracle import tree_ref
+    key = case["id"]
+    cfg = load_config(case["cfg"])
+    sd = make_state_dict(cfg, case["seed"])
+    prompt = torch.from_numpy(G9[key + "_prompt"])
+    P = case["P"]
+    ai, ab, at = tree_inputs(G9, key)
+    seq, mask, pos, pids = tree_ref.get_seq_att_mask(1, ai, ab, at, P, 0)
+    for got, nm in ((seq, "seq"), (mask, "mask"), (pos, "pos"), (pids, "pids")):
+        np.testing.assert_array_equal(got.numpy(), G9[f"{key}_{nm}"])
+    kv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1, case["top_k"], case["top_p"])
+    p1 = kv.forward_tree_attention(seq, prompt, mask, pids, pos.clone())
+    np.testing.assert_allclose(p1.numpy(), G9[key + "_p1"], atol=1e-5)
+    kv.rollback_tree_attention(torch.tensor([0]), torch.from_numpy(G9[key + "_keep"]))
+    np.testing.assert_allclose(kv._past_key_values[-1][0].numpy(), G9[key + "_k_last"], atol=1e-5)
+    np.testing.assert_allclose(kv._prob_history.numpy(), G9[key + "_hist"], atol=1e-5)
+    prefix2 = torch.from_numpy(G9[key + "_prefix2"])
+    ai2, ab2, at2 = tree_inputs(G9, key, "2")
+    seq2, mask2, pos2, pids2 = tree_ref.get_seq_att_mask(1, ai2, ab2, at2, prefix2.shape[1], 0)
+    p2 = kv.forward_tree_attention(seq2, prefix2, mask2, pids2, pos2.clone())
+    np.testing.assert_allclose(p2.numpy(), G9[key + "_p2"], atol=1e-5)
+
+
+@pytest.mark.parametrize("case", G9_META["dp"], ids=[c["id"] for c in G9_META["dp"]])
+def test_acceptance_count_recursion_golden(case):
+    from oracle import tree_ref
+    p, q = torch.from_numpy(G9[case["id"] + "_p"]), torch.from_numpy(G9[case["id"] + "_q"])
+    prob, expect = tree_ref.get_num_acc_prob(p, q, case["m"])
+    np.testing.assert_allclose(prob.numpy(), G9[case["id"] + "_prob"], atol=1e-6)
+    assert abs(float(expect) - case["expect"]) < 1e-5
+    assert [tree_ref.get_expect_cnt_by_thres(prob, th) for th in case["thres"]] == case["counts"]
