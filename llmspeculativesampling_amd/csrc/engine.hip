@@ -718,23 +718,27 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
         sd_set_error("attention: %d keys x %d row groups exceed the LDS score tile", s_max, tab.n_groups);
         return SD_ERR_CAPACITY;
     }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        if constexpr (sizeof(T) == 2 && D >= 32)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D, true>),
+    auto launch = [&](auto kv8, auto tree) -> int {
+        constexpr bool KV8 = decltype(kv8)::value, TREE = decltype(tree)::value;
+        static bool attr = false;                                 // (one flag per instantiation of this lambda)
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_kernel<T, D, KV8, TREE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-        attr = true;
-    }
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_kernel<T, D, KV8, TREE>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer,
+                           out, c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
+        return SD_OK;
+    };
+    using std::true_type;
+    using std::false_type;
     if (tab.kv_fp8) {
-        if constexpr (sizeof(T) == 2 && D >= 32)
-            hipLaunchKernelGGL((attn_kernel<T, D, true>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer,
-                               out, c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
-        else { sd_set_error("fp8 KV needs a 16-bit model with head_dim >= 32"); return SD_ERR_INVALID; }
-    } else
-    hipLaunchKernelGGL((attn_kernel<T, D, false>), dim3(c.n_heads, tab.n_groups, nsplit), dim3(256), lds, st, q, tab, layer, out,
-                       c.n_heads, c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, nsplit, s->attn_part);
+        if constexpr (sizeof(T) == 2 && D >= 32) {
+            if (tab.tree) launch(true_type{}, true_type{}); else launch(true_type{}, false_type{});
+        } else { sd_set_error("fp8 KV needs a 16-bit model with head_dim >= 32"); return SD_ERR_INVALID; }
+    } else {
+        if (tab.tree) launch(false_type{}, true_type{}); else launch(false_type{}, false_type{});
+    }
     if (nsplit > 1)
         hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3(c.n_heads, tab.n_groups), dim3(128), 0, st,
                            (const float *)s->attn_part, tab, out, c.n_heads, nsplit);

@@ -832,7 +832,7 @@ __device__ long long g_att_stamps[16];
 #endif
 // KV8: the arena holds fp8 e4m3 (tab.kv_fp8; 16-bit T and D >= 32 only): keys / values are widened to T in registers
 // (exact), the K scale multiplies the scores and the V scale the output.
-template <typename T, int D, bool KV8 = false>
+template <typename T, int D, bool KV8 = false, bool TREE = false>
 __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
                                                   T *__restrict__ out, int Hq, int Hkv, int arch,
                                                   float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     // whole range.  From here on key indices are local to the chunk.
     // tree verify: every row may see all tab.tree_base cached keys and, among the tree rows of this call, those in its
     // mask; the causal arithmetic below then only bounds the key range (all tree rows), visibility comes from `vis`
-    const bool tree = tab.tree != 0;
+    constexpr bool tree = TREE;                                   // (a template flag: the causal path pays nothing for it)
     const int s_all = tree ? tab.tree_base + tab.n_rows : pos0 + r0 + nr;   // keys visible to the last row of the group
     const int chunk = nsplit > 1 ? (((s_all + nsplit - 1) / nsplit + 15) & ~15) : s_all;
     const int kb = nsplit > 1 ? (int)blockIdx.z * chunk : 0;

@@ -476,7 +476,7 @@ def test_kvcache_model_api_matches_oracle(hip):
     okv.rollback(10)
     assert kv._prob_history.shape == okv._prob_history.shape == (1, 10, cfg.vocab_size)
     assert kv._past_key_values[0][0].shape == okv._past_key_values[0][0].shape
-    for name in ("forward_tree_attention", "beam_rollback", "rollback_tree_attention", "beam_sample"):
+    for name in ("beam_rollback", "beam_sample_with_kv_cache", "beam_sample"):     # the HF-beam-sampling draft side
         with pytest.raises(NotImplementedError):
             getattr(kv, name)()
 
