@@ -15,11 +15,43 @@ import re
 import sys
 from collections import defaultdict
 
+
+def demangle(name, _cache={}):
+    """rocprofv3 prints the kernels whose template arguments include __bf16 / _Float16 mangled (_Z<len><name>I...E) and
+    no demangler in the image knows DF16b: rebuild "name<int, int, ...>" from the length-prefixed name and the
+    Li<n>E / Lb<n>E literals, which is all the tools below match on."""
+    if not name.startswith("_Z"):
+        return name
+    m = re.match(r"_Z(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        rest = rest[:rest.find("Ev") + 1] if "Ev" in rest else rest      # the template list ends before the void return type
+        for tok in re.finditer(r"L([ib])(\d+)E|DF16b|DF16_|f", rest[1:]):
+            if tok.group(0).startswith("L"):
+                args.append(tok.group(2))
+            elif tok.group(0) == "DF16b":
+                args.append("bf16")
+            elif tok.group(0) == "DF16_":
+                args.append("f16")
+            else:
+                args.append("float")
+            if len(args) >= 6:
+                break
+    return f"{base}<{', '.join(args)}>" if args else base
+
+
+
 csv.field_size_limit(1 << 30)
 per = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
-    m = re.match(r"(?:void )?([A-Za-z_0-9:]+(?:<[^(]*?>)?)", r["Kernel_Name"])
+    nm = demangle(r["Kernel_Name"])
+    m = re.match(r"(?:void )?([A-Za-z_0-9:]+(?:<[^(]*?>)?)", nm)
     k = (m.group(1) if m else r["Kernel_Name"])[:80]
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     calls[k].add(r["Dispatch_Id"])

@@ -17,10 +17,42 @@ import re
 import sys
 from collections import defaultdict
 
+
+def demangle(name, _cache={}):
+    """rocprofv3 prints the kernels whose template arguments include __bf16 / _Float16 mangled (_Z<len><name>I...E) and
+    no demangler in the image knows DF16b: rebuild "name<int, int, ...>" from the length-prefixed name and the
+    Li<n>E / Lb<n>E literals, which is all the tools below match on."""
+    if not name.startswith("_Z"):
+        return name
+    m = re.match(r"_Z(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        rest = rest[:rest.find("Ev") + 1] if "Ev" in rest else rest      # the template list ends before the void return type
+        for tok in re.finditer(r"L([ib])(\d+)E|DF16b|DF16_|f", rest[1:]):
+            if tok.group(0).startswith("L"):
+                args.append(tok.group(2))
+            elif tok.group(0) == "DF16b":
+                args.append("bf16")
+            elif tok.group(0) == "DF16_":
+                args.append("f16")
+            else:
+                args.append("float")
+            if len(args) >= 6:
+                break
+    return f"{base}<{', '.join(args)}>" if args else base
+
+
+
 csv.field_size_limit(1 << 30)
 
 
 def short(name):
+    name = demangle(name)
     m = re.match(r"(?:void )?([A-Za-z_0-9:]+(?:<[^(]*?>)?)", name)
     n = m.group(1) if m else name[:60]
     return n[:80]
