@@ -306,6 +306,12 @@ int sd_session_forward_tree(sd_session *s, const int32_t *tokens, const int32_t 
                             int base_len, float *logits_out, long ld_logits, void *stream);
 int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream);
 
+/* Forwards over <= 16 new rows may run the streaming half of every layer as ONE launch whose phases wait for each other
+ * on device-side counters (csrc/chain_kernels.h; same arithmetic as one launch per op).  Every wait is bounded; a wait that
+ * ran into its limit leaves a bit in the status word of the LAST forward, read here (blocking copy; 0 = no wait timed out,
+ * also when that forward took the launch-per-op path). */
+int sd_session_chain_status(sd_session *s, unsigned *status_out);
+
 /* Stream-batched forward: the new rows of up to 16 independent sequences share ONE pass over the
  * weights (same bytes streamed, n_items times the tokens).  Each item names its own session (KV arena), its token
  * buffer `seq` (device int32 indexed by ABSOLUTE position: the rows read seq[pos0 .. pos0+n_new)), its cache length

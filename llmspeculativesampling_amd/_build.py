@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspecdec.so")
 SOURCES = ["sampling.hip", "engine.hip"]
-HEADERS = ["common.h", "model_kernels.h", os.path.join("..", "..", "include", "specdec.h")]
+HEADERS = ["common.h", "model_kernels.h", "small_kernels.h", "chain_kernels.h", os.path.join("..", "..", "include", "specdec.h")]
 
 
 def _hipcc() -> str:

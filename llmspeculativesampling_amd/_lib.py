@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspecdec.so")
+LIB_PATH = os.environ.get("SD_LIBSPECDEC") or os.path.join(_HERE, "libspecdec.so")   # (override: kernel-variant experiments)
 
 SD_OK, SD_ERR_INVALID, SD_ERR_NORM_LOGITS, SD_ERR_PROB, SD_ERR_HIP, SD_ERR_CAPACITY = 0, -1, -2, -3, -4, -5
 SD_F32, SD_BF16, SD_F16 = 0, 1, 2
@@ -103,6 +103,7 @@ SYMBOLS = [
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
     ("sd_session_forward_tree", _I, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), _I, _I, _VP, _L, _VP]),
     ("sd_session_compact_kv", _I, [_VP, _I, _VP, _I, _VP]),
+    ("sd_session_chain_status", _I, [_VP, _VP]),
     ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),
     ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
     ("sd_spec_destroy", _I, [_VP]),

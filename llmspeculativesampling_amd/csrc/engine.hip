@@ -10,6 +10,7 @@
 
 #include "model_kernels.h"
 #include "small_kernels.h"
+#include "chain_kernels.h"
 
 static thread_local char g_err[512] = "";
 void sd_set_error(const char *fmt, ...) {
@@ -38,6 +39,9 @@ struct sd_session {
     void *x, *h, *qbuf, *attn, *act, *ebuf;
     void *x2;           // second residual-stream buffer of the small-model path (the prologue-fused chain ping-pongs)
     float *spart;       // split-K slabs of the small-model path's O / down GEMMs (its head writes s->part meanwhile)
+    void *h2;           // second normalised-operand buffer and the phase counters (+ error word) of the chained layer
+    unsigned *chain_ctr;   // launch (chain_kernels.h): [CH_MAX_PHASES][CH_CTR_WORDS] + 32 words, zeroed per forward
+    int chain_used;        // the last forward took the chained launches (its status word is meaningful)
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
     int kv_fp8;         // the arena holds fp8 e4m3 (sd_session_set_kv_fp8)
@@ -253,7 +257,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
+    size_t x, x2, h, h2, cctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -266,6 +270,8 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.x = take((size_t)rows * c.hidden * es);
     p.x2 = take((size_t)SMALL_MAX_ROWS * c.hidden * es);
     p.h = take(trows * wide * es);
+    p.h2 = take(trows * wide * es);
+    p.cctr = take(((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned));
     p.q = take((size_t)rows * c.hidden * es);
     p.attn = take(trows * c.hidden * es);
     p.act = take(trows * c.inter * es);
@@ -341,6 +347,9 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->head_zero_ld = 0;
     s->last_tile_max = nullptr;
     s->h = s->scratch + p.h;
+    s->h2 = s->scratch + p.h2;
+    s->chain_ctr = (unsigned *)(s->scratch + p.cctr);
+    s->chain_used = 0;
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
     s->act = s->scratch + p.act;
@@ -895,6 +904,83 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
     return SD_OK;
 }
 
+
+// ---- chained layer launch (chain_kernels.h): O -> residual+norm -> gate/up -> down -> residual+norm -> next QKV ----------
+// The per-op path's plans (split counts, workgroup shapes) are kept, so both routes give identical bits.
+static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
+    const sd_model_config &c = s->m->cfg;
+    const char *env = getenv("SD_CHAIN");                              // (read per call: the tests flip it in-process)
+    const int enabled = env ? atoi(env) : 0;
+    if (!enabled || !is16(c.dtype) || !c.fused_layout || tab.contig || s->tp) return false;
+    if (tab.n_rows > 16 || c.hidden % 32 != 0 || c.hidden < 1024) return false;
+    if (c.arch == SD_ARCH_OPT && (!c.opt_pre_ln || embed_dim(c) != c.hidden)) return false;
+    if (!s->m->w.final_norm_w) return false;
+    const int n = tab.n_rows;
+    const GemmPlan po = gemm_plan(c.hidden, q_dim(c), n), pd = gemm_plan(c.hidden, c.inter, n);
+    if (po.tiled || pd.tiled || gemm_plan(qkv_cols(c), c.hidden, n).tiled || gemm_plan(gu_cols(c), c.hidden, n).tiled) return false;
+    if ((size_t)po.S * 16 * c.hidden > s->part_floats || (size_t)pd.S * 16 * c.hidden > s->spart_floats) return false;
+    return true;
+}
+
+template <typename H>
+static int launch_chain(sd_session *s, const RowTab &tab, int l, int rn_threads, unsigned epoch, hipStream_t st) {
+    sd_model *m = s->m;
+    const sd_model_config &c = m->cfg;
+    const int Hd = c.hidden, I = c.inter, L = c.n_layers, n = tab.n_rows;
+    const bool llama = c.arch == SD_ARCH_LLAMA;
+    const GemmPlan po = gemm_plan(Hd, q_dim(c), n), pd = gemm_plan(Hd, I, n);
+    ChainArgs<H> a = {};
+    a.M = n; a.hidden = Hd; a.rn_threads = rn_threads; a.eps = c.norm_eps;
+    a.cos_t = (const H *)m->w.rope_cos; a.sin_t = (const H *)m->w.rope_sin;
+    a.Hq = c.n_heads; a.Hkv = c.n_kv_heads; a.D = c.head_dim; a.q_scale = 1.0f / sqrtf((float)c.head_dim);
+    a.ctr = s->chain_ctr; a.err = s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS; a.epoch = epoch;
+    static const unsigned dbg_flags = getenv("SD_CHAIN_FLAGS") ? (unsigned)atoi(getenv("SD_CHAIN_FLAGS")) : 0u;
+    a.flags = dbg_flags;
+    a.tab = tab;
+    int blk = 0, np = 0;
+    auto add = [&](ChainPhase ph) {
+        ph.blk0 = blk;
+        ph.wait_slot = np ? np - 1 : -1;
+        ph.wait_n = np ? a.ph[np - 1].nblk : 0;
+        ph.sig_slot = np;
+        blk += ph.nblk;
+        a.ph[np++] = ph;
+    };
+    auto gemm = [&](int epi, const void *W, const void *X, float *part, int N, int K, int S, int ksp, void *out,
+                    const void *bias, int n_out, int layer) {
+        ChainPhase ph = {};
+        ph.type = CH_GEMM; ph.epi = epi; ph.nblk = (N / 16) * S;
+        ph.W = (const u32x4 *)W; ph.X = X; ph.part = part; ph.N = N; ph.K = K; ph.SB = S; ph.ks_per_blk = ksp;
+        ph.out = out; ph.bias = bias; ph.n_out = n_out; ph.layer = layer;
+        add(ph);
+    };
+    auto rn = [&](const float *slab, int S, const void *bias, const void *nw, const void *nb, int mode, void *hout) {
+        ChainPhase ph = {};
+        ph.type = CH_RN; ph.nblk = n;
+        ph.xres = s->x; ph.slab = slab; ph.S = S; ph.stride_s = (size_t)16 * Hd; ph.bias = bias; ph.nw = nw; ph.nb = nb;
+        ph.mode = mode; ph.out = hout;
+        add(ph);
+    };
+    gemm(EPI_PART, m->wo[l], s->attn, s->part, Hd, q_dim(c), po.S, po.ksp, nullptr, nullptr, 0, l);
+    rn(s->part, po.S, m->bo[l], m->n2w[l], m->n2b[l], RES_PRE, s->h2);
+    gemm(llama ? EPI_ACT_SILU : EPI_ACT_RELU, m->wgu[l], s->h2, nullptr, gu_cols(c), Hd, 1, Hd / 32, s->act, m->bfc1[l], I, l);
+    gemm(EPI_PART, m->wdown[l], s->act, s->spart, Hd, I, pd.S, pd.ksp, nullptr, nullptr, 0, l);
+    if (l + 1 < L) {
+        rn(s->spart, pd.S, m->bfc2[l], m->n1w[l + 1], m->n1b[l + 1], RES_PRE, s->h);
+        gemm(llama ? EPI_QKV_ROPE : EPI_QKV_PLAIN, m->wqkv[l + 1], s->h, nullptr, qkv_cols(c), Hd, 1, Hd / 32, s->qbuf,
+             m->bqkv[l + 1], 0, l + 1);
+    } else {
+        rn(s->spart, pd.S, m->bfc2[l], m->w.final_norm_w, m->w.final_norm_b, RES_PRE, s->h);
+    }
+    a.ph[np - 1].sig_slot = -1;                                        // the launch boundary publishes the last phase
+    a.n_phases = np;
+    ProfScope ps(s, PC_GEMM, st);
+    if (llama) hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_LLAMA>), dim3(blk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_OPT>), dim3(blk), dim3(256), 0, st, a);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
 template <typename T>
 static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits,
                         hipStream_t st) {
@@ -983,10 +1069,18 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         }
     }
 
+    bool chain = false;
+    s->chain_used = 0;
+    if constexpr (!std::is_same<T, float>::value) {
+        chain = chain_path_ok(s, tab);
+        s->chain_used = chain ? 1 : 0;
+        if (chain)
+            SD_HIP_CHECK(hipMemsetAsync(s->chain_ctr, 0, ((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned), st));
+    }
     for (int l = 0; l < L; ++l) {
         // qkv projection -> rope / scale -> q buffer + in-place KV append (fused into the GEMM's epilogue unless the
         // row count takes the tiled kernel, which leaves slabs for the stand-alone epilogue)
-        if (l == 0 && qkv0_done) {
+        if ((l == 0 && qkv0_done) || (l > 0 && chain)) {              // (the chained launch of layer l - 1 ran this layer's QKV)
         } else if (fused && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
@@ -1015,6 +1109,12 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             }
             if (rc != SD_OK) return rc;
             SD_LAUNCH_CHECK();
+        }
+        if constexpr (!std::is_same<T, float>::value) {
+            if (chain) {
+                if ((rc = launch_chain<T>(s, tab, l, rn_threads, (unsigned)(l + 1), st)) != SD_OK) return rc;
+                continue;
+            }
         }
         // output projection + residual (+ norm feeding the MLP)
         if ((rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
@@ -1236,6 +1336,14 @@ __global__ void kv_compact_kernel(char *kv, int max_seq, int row_bytes, int base
         const int j = i / n16, c = i - j * n16;
         reinterpret_cast<uint4 *>(arena + (size_t)(base + j) * row_bytes)[c] = reinterpret_cast<const uint4 *>(sm)[i];
     }
+}
+
+extern "C" int sd_session_chain_status(sd_session *s, unsigned *status_out) {
+    SD_REQUIRE(s && status_out, "sd_session_chain_status: null argument");
+    *status_out = 0;
+    if (!s->chain_used) return SD_OK;
+    SD_HIP_CHECK(hipMemcpy(status_out, s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return SD_OK;
 }
 
 extern "C" int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream) {

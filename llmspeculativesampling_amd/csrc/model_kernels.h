@@ -137,12 +137,36 @@ __device__ __forceinline__ void store4(H *dst, float a, float b, float c, float 
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
+// Write-through (sc1) stores for data another workgroup of the SAME launch reads (chain_kernels.h): a relaxed agent-scope
+// atomic store is a plain global_store with the sc1 bit, so the bytes are in memory (not in this XCD's L2 only) once the
+// wave's vmcnt drains; pointers are 8-byte aligned at every call site.
+__device__ __forceinline__ void store8_wt(void *dst, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool WT>
+__device__ __forceinline__ void store_f32x4(float *dst, f32x4 v) {
+    if constexpr (WT) {
+        store8_wt(dst, uint2{__float_as_uint(v[0]), __float_as_uint(v[1])});
+        store8_wt(dst + 2, uint2{__float_as_uint(v[2]), __float_as_uint(v[3])});
+    } else {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+    }
+}
+template <bool WT, typename H>
+__device__ __forceinline__ void store4_maybe_wt(H *dst, float a, float b, float c, float d) {
+    const H v[4] = {(H)a, (H)b, (H)c, (H)d};
+    if constexpr (WT) store8_wt(dst, *reinterpret_cast<const uint2 *>(v));
+    else *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
+}
+
 // One fold step of the streaming GEMMs' epilogue: red[wave][pp][lane] holds the 4 waves' accumulators of PT tiles; the
 // folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
 // gemm_small (small_kernels.h).
-template <int MT, int EPI, int NTW, int PT, typename H = bf16_t>
+// E: GemmEpiT<H>, or any view with the same member names (chain_kernels.h passes one whose `tab` is a reference).
+template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
-                                                   int N, int sb, int ntg, const GemmEpiT<H> &e) {
+                                                   int N, int sb, int ntg, const E &e) {
     auto folded = [&](int pp, int l) -> f32x4 {
         return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
     };
@@ -150,8 +174,7 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
         if (threadIdx.x < PT * 64) {
             const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
             const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
-            if (m < M)
-                *reinterpret_cast<f32x4 *>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4) = folded(pp, l);
+            if (m < M) store_f32x4<WT>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4, folded(pp, l));
         }
     } else if constexpr (EPI == EPI_HEAD) {
         static_assert(EPI != EPI_HEAD || (MT == 1 && NTW == 1 && PT == 1), "EPI_HEAD: one 16-row tile, one n-tile per workgroup");
@@ -182,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                     const float gj = rnd<H>(g[c]), uj = rnd<H>(u[c]);
                     a[c] = rnd<H>(gj / (1.0f + expf(-gj))) * uj;       // silu(gate) * up (modeling_llama.py:220)
                 }
-                store4(e.out + xoff<H>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
+                store4_maybe_wt<WT>(e.out + xoff<H>(m, nt * 8 + (l >> 4) * 4, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
@@ -197,7 +220,7 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
                     const float f = rnd<H>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
                     a[c] = f > 0.f ? f : 0.f;
                 }
-                store4(e.out + xoff<H>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
+                store4_maybe_wt<WT>(e.out + xoff<H>(m, col, e.n_out), a[0], a[1], a[2], a[3]);
             }
         }
     } else {
@@ -548,6 +571,9 @@ template <typename T>
 __device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, const T *__restrict__ w,
                                          const T *__restrict__ b, float eps, int kind, float *red,
                                          T *__restrict__ hbase, int row) {
+    // (no fused multiply-adds here: the same statistics are computed by other kernels - small_kernels.h, chain_kernels.h -
+    // that must give the same bits, and what the compiler contracts depends on the code around an expression)
+#pragma clang fp contract(off)
     float a = 0.f, a2 = 0.f;
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         const float v = xs[i];
@@ -655,6 +681,7 @@ __global__ __launch_bounds__(1024) void residual_norm_kernel(T *__restrict__ x, 
                                                             size_t stride_s, int H, const T *__restrict__ bias,
                                                             const T *__restrict__ w, const T *__restrict__ b,
                                                             float eps, int kind, int mode, T *__restrict__ h) {
+#pragma clang fp contract(off)                                    // see norm_row
     __shared__ float red[32];
     RN_STAMP(0);
     const int row = blockIdx.x;

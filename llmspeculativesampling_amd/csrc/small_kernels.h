@@ -42,6 +42,7 @@ template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, const bf16_t *__restrict__ X,
                                                  float *__restrict__ part, int M, int N, int K, int SB,
                                                  int ks_per_blk, GemmEpi e, SmallPro p) {
+#pragma clang fp contract(off)                                    // see norm_row (model_kernels.h)
     constexpr int KSW = 8;                                        // k-steps of weights a wave keeps in flight
     __shared__ f32x4 red[4][1][64];
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];

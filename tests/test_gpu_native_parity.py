@@ -467,6 +467,55 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     assert float((got - want[: got.shape[0]]).abs().max()) <= 0.04 * float(want.abs().max())
 
 
+# --------------------------------------------------------------------------- chained layer launch (chain_kernels.h)
+CHAIN_CFGS = {
+    "llama_h1024": dict(arch="llama", vocab_size=16384, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3,
+                        num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=256, rms_norm_eps=1e-5),
+    "llama_gqa_h2048": dict(arch="llama", vocab_size=16384, hidden_size=2048, intermediate_size=5632, num_hidden_layers=2,
+                            num_attention_heads=16, num_key_value_heads=4, max_position_embeddings=256, rms_norm_eps=1e-6),
+    "opt_h1024": dict(arch="opt", vocab_size=16384, hidden_size=1024, ffn_dim=4096, num_hidden_layers=3,
+                      num_attention_heads=16, max_position_embeddings=256, do_layer_norm_before=True,
+                      word_embed_proj_dim=1024),
+}
+
+
+def _chain_status(hip, ses):
+    import ctypes as C
+    w = C.c_uint(0)
+    assert hip.lib.sd_session_chain_status(ses.handle, C.byref(w)) == 0, hip.lib.sd_last_error().decode()
+    return w.value
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("name", list(CHAIN_CFGS))
+def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, name, dtype):
+    """SD_CHAIN=1: O -> residual+norm -> gate/up -> down -> residual+norm -> next QKV run as phases of ONE launch per
+    layer (workgroups of a phase prefetch their weights, then wait for the phase before them).  Arithmetic and split
+    plans are the per-op path's, so logits and every KV row must be bit-identical for 1..16 new rows, repeatedly (a stale
+    read across XCDs would show as a mismatch), and no wait may have hit its time limit."""
+    cfg = ModelConfig(**CHAIN_CFGS[name])
+    sd = make_state_dict(cfg, 91, dtype=dtype)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    ids = torch.from_numpy(np.random.default_rng(23).integers(3, cfg.vocab_size, size=(1, 120))).to(torch.int32).cuda()[0]
+    steps = (5, 1, 5, 16, 3, 5, 5, 2, 5, 9)
+    outs = {}
+    for flag in ("0", "1"):
+        os.environ["SD_CHAIN"] = flag
+        try:
+            ses = m.new_session(160)
+            ses.forward(ids[:40], 0)
+            got, pos = [], 40
+            for q in steps:
+                got.append(ses.forward(ids[pos:pos + q], q).clone())
+                pos += q
+            outs[flag] = (torch.cat(got), ses.kv[:, :, :, :pos].clone())
+            assert _chain_status(hip, ses) == 0
+        finally:
+            os.environ.pop("SD_CHAIN", None)
+    assert torch.equal(outs["1"][1], outs["0"][1]), "KV rows differ"
+    assert torch.equal(outs["1"][0], outs["0"][0]), "logits differ"
+
+
 # --------------------------------------------------------------------------- config 3: OPT in bf16 end to end
 def test_opt_bf16_pair_end_to_end_vs_oracle(hip):
     """BASELINE config 3's family (OPT draft -> OPT target, bf16): OPT keeps its logits in the weight dtype, so the
