@@ -910,7 +910,7 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
 static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
     const char *env = getenv("SD_CHAIN");                              // (read per call: the tests flip it in-process)
-    const int enabled = env ? atoi(env) : 0;
+    const int enabled = env ? atoi(env) : 0;                           // 1: in-order chained launch, 2: persistent engine
     if (!enabled || !is16(c.dtype) || !c.fused_layout || tab.contig || s->tp) return false;
     if (tab.n_rows > 16 || c.hidden % 32 != 0 || c.hidden < 1024) return false;
     if (c.arch == SD_ARCH_OPT && (!c.opt_pre_ln || embed_dim(c) != c.hidden)) return false;
@@ -919,8 +919,17 @@ static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
     const GemmPlan po = gemm_plan(c.hidden, q_dim(c), n), pd = gemm_plan(c.hidden, c.inter, n);
     if (po.tiled || pd.tiled || gemm_plan(qkv_cols(c), c.hidden, n).tiled || gemm_plan(gu_cols(c), c.hidden, n).tiled) return false;
     if ((size_t)po.S * 16 * c.hidden > s->part_floats || (size_t)pd.S * 16 * c.hidden > s->spart_floats) return false;
+    if (enabled == 2) {
+        // the engine's loader deals an item's tiles to four consumers in turn: every k-slab must be full-size and a
+        // multiple of 4 k-steps
+        const int shapes[4][3] = {{q_dim(c) / 32, po.ksp, po.S}, {c.inter / 32, pd.ksp, pd.S}, {c.hidden / 32, c.hidden / 32, 1},
+                                  {c.hidden / 32, c.hidden / 32, 1}};
+        for (auto &sh : shapes)
+            if (sh[1] % 4 != 0 || sh[0] != sh[1] * sh[2]) return false;
+    }
     return true;
 }
+static int chain_mode() { const char *env = getenv("SD_CHAIN"); return env ? atoi(env) : 0; }
 
 template <typename H>
 static int launch_chain(sd_session *s, const RowTab &tab, int l, int rn_threads, unsigned epoch, hipStream_t st) {
@@ -975,7 +984,22 @@ static int launch_chain(sd_session *s, const RowTab &tab, int l, int rn_threads,
     a.ph[np - 1].sig_slot = -1;                                        // the launch boundary publishes the last phase
     a.n_phases = np;
     ProfScope ps(s, PC_GEMM, st);
-    if (llama) hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_LLAMA>), dim3(blk), dim3(256), 0, st, a);
+    if (chain_mode() == 2) {
+        // one engine workgroup per CU (its LDS ring leaves no room for a second one), all resident at once
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            SD_HIP_CHECK(hipGetDevice(&dev));
+            SD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(engine_kernel<H, SD_ARCH_LLAMA>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EngShared)));
+            SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(engine_kernel<H, SD_ARCH_OPT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EngShared)));
+        }
+        SD_REQUIRE(cus >= n, "engine: fewer CUs than rows");
+        if (llama) hipLaunchKernelGGL((engine_kernel<H, SD_ARCH_LLAMA>), dim3(cus), dim3(EN_THREADS), sizeof(EngShared), st, a);
+        else hipLaunchKernelGGL((engine_kernel<H, SD_ARCH_OPT>), dim3(cus), dim3(EN_THREADS), sizeof(EngShared), st, a);
+    } else if (llama) hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_LLAMA>), dim3(blk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_OPT>), dim3(blk), dim3(256), 0, st, a);
     SD_LAUNCH_CHECK();
     return SD_OK;

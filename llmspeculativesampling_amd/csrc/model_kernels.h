@@ -166,20 +166,22 @@ __device__ __forceinline__ void store4_maybe_wt(H *dst, float a, float b, float 
 // E: GemmEpiT<H>, or any view with the same member names (chain_kernels.h passes one whose `tab` is a reference).
 template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
-                                                   int N, int sb, int ntg, const E &e) {
+                                                   int N, int sb, int ntg, const E &e, int tid_ = -1) {
+    // tid_: the calling wave's threads counted from 0 (the engine's epilogue wave is not the workgroup's first)
+    const int tidx = tid_ >= 0 ? tid_ : (int)threadIdx.x;
     auto folded = [&](int pp, int l) -> f32x4 {
         return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
     };
     if constexpr (EPI == EPI_PART) {
-        if (threadIdx.x < PT * 64) {
-            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+        if (tidx < PT * 64) {
+            const int pp = tidx >> 6, l = tidx & 63, q = fs * PT + pp;
             const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
             if (m < M) store_f32x4<WT>(part + ((size_t)sb * Mpad + m) * N + nt * 16 + (l >> 4) * 4, folded(pp, l));
         }
     } else if constexpr (EPI == EPI_HEAD) {
         static_assert(EPI != EPI_HEAD || (MT == 1 && NTW == 1 && PT == 1), "EPI_HEAD: one 16-row tile, one n-tile per workgroup");
-        if (threadIdx.x < 64) {                                   // one whole wave: lanes l, l^16, l^32, l^48 share row m
-            const int l = threadIdx.x, m = l & 15, nt = ntg;
+        if (tidx < 64) {                                   // one whole wave: lanes l, l^16, l^32, l^48 share row m
+            const int l = tidx, m = l & 15, nt = ntg;
             const f32x4 r = folded(0, l);
             float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
             int bad = (r[0] != r[0]) | (r[1] != r[1]) | (r[2] != r[2]) | (r[3] != r[3]);
@@ -194,8 +196,8 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
         }
     } else if constexpr (EPI == EPI_ACT_SILU) {
         // weights interleaved 8 gate rows / 8 up rows per tile: quads 0,1 = gate cols, quads 2,3 = the same up cols
-        if (threadIdx.x < PT * 32) {
-            const int pp = threadIdx.x >> 5, l = threadIdx.x & 31, q = fs * PT + pp;
+        if (tidx < PT * 32) {
+            const int pp = tidx >> 5, l = tidx & 31, q = fs * PT + pp;
             const int m = (q % MT) * 16 + (l & 15), nt = ntg * NTW + q / MT;
             if (m < M) {
                 const f32x4 g = folded(pp, l), u = folded(pp, l + 32);
@@ -209,8 +211,8 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
             }
         }
     } else if constexpr (EPI == EPI_ACT_RELU) {
-        if (threadIdx.x < PT * 64) {
-            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+        if (tidx < PT * 64) {
+            const int pp = tidx >> 6, l = tidx & 63, q = fs * PT + pp;
             const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
             if (m < M) {
                 const f32x4 r = folded(pp, l);
@@ -227,8 +229,8 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
         // QKV: bias, RoPE (rows pair-interleaved inside each q/k head: d, d+D/2, d+1, d+1+D/2, ...) or the OPT
         // q pre-scale, then q -> buffer and K/V rows appended in place at positions pos0 + m.
         const int hd = e.D >> 1;
-        if (threadIdx.x < PT * 64) {
-            const int pp = threadIdx.x >> 6, l = threadIdx.x & 63, q = fs * PT + pp;
+        if (tidx < PT * 64) {
+            const int pp = tidx >> 6, l = tidx & 63, q = fs * PT + pp;
             const int m = (q % MT) * 16 + (l & 15), col = (ntg * NTW + q / MT) * 16 + (l >> 4) * 4;
             if (m < M) {
                 const f32x4 r = folded(pp, l);

@@ -486,9 +486,10 @@ def _chain_status(hip, ses):
     return w.value
 
 
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["inorder", "engine"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("name", list(CHAIN_CFGS))
-def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, name, dtype):
+def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, name, dtype, mode):
     """SD_CHAIN=1: O -> residual+norm -> gate/up -> down -> residual+norm -> next QKV run as phases of ONE launch per
     layer (workgroups of a phase prefetch their weights, then wait for the phase before them).  Arithmetic and split
     plans are the per-op path's, so logits and every KV row must be bit-identical for 1..16 new rows, repeatedly (a stale
@@ -499,7 +500,7 @@ def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, na
     ids = torch.from_numpy(np.random.default_rng(23).integers(3, cfg.vocab_size, size=(1, 120))).to(torch.int32).cuda()[0]
     steps = (5, 1, 5, 16, 3, 5, 5, 2, 5, 9)
     outs = {}
-    for flag in ("0", "1"):
+    for flag in ("0", mode):
         os.environ["SD_CHAIN"] = flag
         try:
             ses = m.new_session(160)
@@ -512,8 +513,8 @@ def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, na
             assert _chain_status(hip, ses) == 0
         finally:
             os.environ.pop("SD_CHAIN", None)
-    assert torch.equal(outs["1"][1], outs["0"][1]), "KV rows differ"
-    assert torch.equal(outs["1"][0], outs["0"][0]), "logits differ"
+    assert torch.equal(outs[mode][1], outs["0"][1]), "KV rows differ"
+    assert torch.equal(outs[mode][0], outs["0"][0]), "logits differ"
 
 
 # --------------------------------------------------------------------------- config 3: OPT in bf16 end to end
