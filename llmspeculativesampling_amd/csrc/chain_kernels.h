@@ -361,6 +361,9 @@ __device__ __forceinline__ void chain_arrive(unsigned *ctr, int p, int g, int n_
 #ifndef EN_XB
 #define EN_XB 3                                              // batches of 4 k-steps of activations a consumer requests ahead
 #endif
+#ifndef EN_NT
+#define EN_NT " nt"                                          // cache policy of the LDS-DMA weight loads
+#endif
 #define EN_RB 2                                              // items whose four accumulators may wait for the epilogue wave
 #define EN_THREADS (64 * (5 + EN_NL))                        // waves 0..3: consumers; then the loaders; last: epilogues
 
@@ -391,7 +394,7 @@ __device__ __forceinline__ void en_cbar(EngShared &S, unsigned &gen) {
 // one 1 KiB tile HBM -> LDS: lane l's 16 bytes at gsrc go to lds_dst + 16 l (M0 carries the wave-uniform LDS address)
 __device__ __forceinline__ void glds16(const u32x4 *gsrc, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" EN_NT "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
