@@ -634,6 +634,41 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(RowTab tab, const T *__
     const int tok = min(max(tab_tok(tab, row, pos), 0), vocab - 1);   // see embed_kernel
     const T *src = table + (size_t)tok * H;
     const T *ps = pos_table ? pos_table + (size_t)(pos + pos_off) * H : nullptr;
+    if constexpr (sizeof(T) == 2) {
+        // 16-byte loads, all of a thread's in flight at once (the row sits in a rarely touched page of a table of
+        // hundreds of MB: with 2-byte loads in a loop the 5-row launch took 18 us)
+        if ((H & 7) == 0) {
+            constexpr int MAXV = 4;                               // H <= 8192: 1024 vectors of 8 over 256 threads
+            u32x4 ev[MAXV], pv[MAXV];
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int i = (threadIdx.x + j * 256) * 8;
+                if (i < H) {
+                    ev[j] = *reinterpret_cast<const u32x4 *>(src + i);
+                    if (ps) pv[j] = *reinterpret_cast<const u32x4 *>(ps + i);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                const int i = (threadIdx.x + j * 256) * 8;
+                if (i < H) {
+                    const T *e8 = reinterpret_cast<const T *>(&ev[j]), *p8 = reinterpret_cast<const T *>(&pv[j]);
+                    T o8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float v = to_f(e8[u]);
+                        if (ps) v = rnd<T>(v + to_f(p8[u]));
+                        o8[u] = from_f<T>(v);
+                        xs[i + u] = v;
+                    }
+                    *reinterpret_cast<u32x4 *>(x + (size_t)row * H + i) = *reinterpret_cast<const u32x4 *>(o8);
+                }
+            }
+            __syncthreads();
+            norm_row<T>(xs, H, w, b, eps, kind, red, h, row);
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < H; i += blockDim.x) {
         float v = to_f(src[i]);
         if (ps) v = rnd<T>(v + to_f(ps[i]));
