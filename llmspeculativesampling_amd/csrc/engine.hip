@@ -1565,7 +1565,12 @@ extern "C" int sd_accept_scan(const float *p_hist, const float *q_hist, long ld,
 int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                             int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, uint64_t seed,
                             uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
-                            void *stream);
+                            void *stream, void *cand_lists);
+size_t sd_norm_candrow_bytes(int rows);
+int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
+                       const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
+                       sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode, const void *target_lists,
+                       hipStream_t st);
 
 // feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows, all of them from the
 // final call (a chunk never ends inside the logits rows), so that call's output slab can be handed to the norm as is
@@ -1615,14 +1620,19 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         if ((rc = sd_norm_rows_with_tiles(sp->draft->last_logits, 1, V, sp->draft->last_logits_ld, sp->temperature, sp->top_k,
                                           sp->top_p, sp->draft->last_logits_round | storage_mode(sp->draft->m), q_row, sp->ld, sp->err + i, seed_draft,
                                           draw_draft0 + (uint64_t)i, sp->seq + upto, sp->err + g + i, sp->norm_ws,
-                                          sp->draft->last_tile_max, stream)) != SD_OK)
+                                          sp->draft->last_tile_max, stream, nullptr)) != SD_OK)
             return rc;
     }
     if (sp->timing) { SD_HIP_CHECK(hipEventRecord(sp->ev[1], st)); SD_HIP_CHECK(hipEventRecord(sp->ev[2], st)); }
+    // the target rows' candidate lists (behind the CandRows of the workspace) let the residual / bonus sample skip its
+    // passes over V; they exist when all gamma + 1 rows of this iteration are normalised here
+    static const int sparse_on = getenv("SD_SPARSE_RESAMPLE") ? atoi(getenv("SD_SPARSE_RESAMPLE")) : 1;
+    void *lists = nullptr;
     // ---- target: every uncached row in one pass (the whole prompt on the first call), logits for the last gamma+1
     {
         const int upto = L + g;
         const int rows = std::min(upto - target_len, g + 1);
+        if (sparse_on && sp->norm_ws && rows == g + 1) lists = (char *)sp->norm_ws + sd_norm_candrow_bytes(g + 1);
         float *p_rows = sp->p_hist + (size_t)(upto - rows) * sp->ld;
         sp->target->want_raw_logits = 1;
         sp->target->head_zero_rows = tiles_ok ? p_rows : nullptr;
@@ -1634,18 +1644,24 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
         if ((rc = sd_norm_rows_with_tiles(sp->target->last_logits, rows, V, sp->target->last_logits_ld, sp->temperature,
                                           sp->top_k, sp->top_p, sp->target->last_logits_round | storage_mode(sp->target->m), p_rows,
                                           sp->ld, sp->err + 2 * g,
-                                          0, 0, nullptr, nullptr, sp->norm_ws, sp->target->last_tile_max, stream)) != SD_OK)
+                                          0, 0, nullptr, nullptr, sp->norm_ws, sp->target->last_tile_max, stream, lists)) != SD_OK)
             return rc;
     }
     if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[3], st));
     // ---- accept scan + residual / bonus sample
-    if ((rc = sd_accept_scan(sp->p_hist, sp->q_hist, sp->ld, sp->seq, L, g, r_const, seed_accept, draw_scan0, sp->res_dev, stream)) != SD_OK)
-        return rc;
     // p - q, max_fn and the draw are in the rows' dtype when both models keep 16-bit rows
     const int res_mode = storage_mode(sp->target->m) == storage_mode(sp->draft->m) ? storage_mode(sp->target->m) : 0;
-    if ((rc = sd_resample_with_errors(sp->p_hist, sp->q_hist, sp->ld, V, sp->seq, g, seed_accept, draw_resample, sp->res_dev,
-                                      sp->err, 3 * g + 1, res_mode, st)) != SD_OK)
-        return rc;
+    if (lists) {
+        if ((rc = sd_accept_resample(sp->p_hist, sp->q_hist, sp->ld, V, sp->seq, L, g, r_const, seed_accept, draw_scan0,
+                                     draw_resample, sp->res_dev, sp->err, 3 * g + 1, res_mode, lists, st)) != SD_OK)
+            return rc;
+    } else {
+        if ((rc = sd_accept_scan(sp->p_hist, sp->q_hist, sp->ld, sp->seq, L, g, r_const, seed_accept, draw_scan0, sp->res_dev, stream)) != SD_OK)
+            return rc;
+        if ((rc = sd_resample_with_errors(sp->p_hist, sp->q_hist, sp->ld, V, sp->seq, g, seed_accept, draw_resample, sp->res_dev,
+                                          sp->err, 3 * g + 1, res_mode, st)) != SD_OK)
+            return rc;
+    }
     SD_HIP_CHECK(hipMemcpyAsync(res_host, sp->res_dev, sizeof(sd_accept_result), hipMemcpyDeviceToHost, st));
     if (tok_host)       // optional second copy; the result block already carries the drafted tokens and the next one
         SD_HIP_CHECK(hipMemcpyAsync(tok_host, sp->seq + L, sizeof(int32_t) * (size_t)(g + 2), hipMemcpyDeviceToHost, st));

@@ -212,6 +212,11 @@ struct NormTab {
 #define CAND_MAXIT 4
 struct CandHdr { int count; int bad; float maxv; int pad; };
 struct CandRow { CandHdr hdr[NB_SPLIT]; uint2 cand[NB_SPLIT][CAND_CAP]; };
+// The non-zero entries of one normalised row, as norm_probs_kernel's list mode leaves them (n < 0: no list - the row was
+// not produced in list mode, holds more than SD_CL_CAP entries, or is invalid): what the residual / bonus sample of the
+// native iteration works on instead of two passes over V.
+#define SD_CL_CAP 128
+struct CandList { int n; int idx[SD_CL_CAP]; float prob[SD_CL_CAP]; };
 
 __global__ __launch_bounds__(256) void norm_cand_kernel(const float *__restrict__ logits, long ld_in, int V,
                                                        float temperature, int top_k, int bf16_round,
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
                                                        uint64_t seed, uint64_t draw, int *__restrict__ tok_out,
                                                        int *__restrict__ samp_err, const CandRow *__restrict__ ws,
                                                        NormTab tab, int use_tab, int filter_only,
-                                                       const float *__restrict__ tile_max) {
+                                                       const float *__restrict__ tile_max, CandList *__restrict__ cl_out) {
     // tile_max (or NULL): the lm_head's epilogue (EPI_HEAD, model_kernels.h) left the maximum of every 16-column tile
     // of the logits row (NaN when the tile holds one) in tile_max[row][V/16] and cleared the output row; the candidates
     // for 1 <= top_k <= 64 are then found from V/16 maxima + the few tiles that can hold one, without a pass over V.
@@ -326,6 +331,8 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         samp_err = tab.samp_err[blockIdx.x];
     }
     const uint32_t neg_inf_key = 0x007fffffu;                     // fkey(-inf)
+    CandList *cl = (cl_out && !use_tab) ? cl_out + row : nullptr;
+    if (cl && tid == 0) cl->n = -1;                               // (list mode below overwrites it)
 
     auto load_z = [&](int i) -> float {
         return scaled_logit(x[i], temperature, bf16_round);      // utils.py:197
@@ -751,6 +758,10 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         };
         for (int c = tid; c < kept; c += NTX)
             o[S.sidx[c]] = filter_only ? funkey(S.skey[c]) : PL(S.skey[c]);
+        if (cl && !filter_only && kept <= SD_CL_CAP) {
+            for (int c = tid; c < kept; c += NTX) { cl->idx[c] = S.sidx[c]; cl->prob[c] = PL(S.skey[c]); }
+            if (tid == 0) cl->n = kept;                           // (same thread as the -1 above: program order)
+        }
         STAMP(5);
         if (SAMPLE) {
             // multinomial(p, 1) == argmax_i p_i / e_i over the support (zero-probability entries give 0 and never
@@ -1106,7 +1117,7 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
                        const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
                        void *stream, const NormTab *tabp = nullptr, int filter_only = 0,
-                       const float *tile_max = nullptr) {
+                       const float *tile_max = nullptr, CandList *cl_out = nullptr) {
     NormTab tab = {};
     const int use_tab = tabp != nullptr;
     if (tabp) tab = *tabp;
@@ -1142,12 +1153,12 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
     if (do_sample)
         hipLaunchKernelGGL(norm_probs_kernel<true>, dim3(rows), dim3(nthr), lds_k, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged_k, probs_out, ld_out, err_flag, noise,
-                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0, tile_max);
+                           seed, draw, tok_out, samp_err, (const CandRow *)ws, tab, use_tab, 0, tile_max, cl_out);
     else
         hipLaunchKernelGGL(norm_probs_kernel<false>, dim3(rows), dim3(nthr), lds_k, (hipStream_t)stream, logits, ld_in, V,
                            temperature, top_k, top_p, bf16_round_logits, staged_k, probs_out, ld_out, err_flag,
                            (const float *)nullptr, (uint64_t)0, (uint64_t)0, (int *)nullptr, (int *)nullptr,
-                           (const CandRow *)ws, tab, use_tab, filter_only, tile_max);
+                           (const CandRow *)ws, tab, use_tab, filter_only, tile_max, cl_out);
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
@@ -1157,10 +1168,12 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
 int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                             int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, uint64_t seed,
                             uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
-                            void *stream) {
+                            void *stream, void *cand_lists) {
     return launch_norm(logits, rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, probs_out, ld_out, err_flag,
-                       tok_out != nullptr, nullptr, seed, draw, tok_out, samp_err, workspace, stream, nullptr, 0, tile_max);
+                       tok_out != nullptr, nullptr, seed, draw, tok_out, samp_err, workspace, stream, nullptr, 0, tile_max,
+                       static_cast<CandList *>(cand_lists));
 }
+size_t sd_cand_list_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandList); }
 
 // top_k_top_p_filter on its own (utils.py:152-179): out = logit where kept, -inf where dropped (out != logits).
 extern "C" int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p,
@@ -1171,7 +1184,9 @@ extern "C" int sd_topk_topp_filter(const float *logits, int rows, int V, long ld
                        nullptr, nullptr, stream, nullptr, 1);
 }
 
-extern "C" size_t sd_norm_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandRow); }
+// (+ one CandList per row behind the CandRows: the native iteration keeps the target rows' candidate lists there)
+extern "C" size_t sd_norm_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * (sizeof(CandRow) + sizeof(CandList)); }
+size_t sd_norm_candrow_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandRow); }
 
 extern "C" int sd_norm_probs(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
                              float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
@@ -1267,6 +1282,133 @@ int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, i
     hipLaunchKernelGGL(resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, gamma,
                        (const float *)nullptr, philox_seed, draw_index, res, (int32_t *)nullptr, err_flags, n_err,
                        mode_dt(dtype_mode));
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// accept scan + residual / bonus sample of one native iteration in ONE launch, the sample working on the candidate list of
+// target row n (its <= SD_CL_CAP non-zero probabilities) instead of two passes over V: every weight outside p_n's support is
+// zero, so sums, arg-maxima and the < 1e-9 fix-up only ever see list entries.  The result is bit-identical to
+// accept_scan_kernel + resample_kernel: the normaliser is summed through the same 1024 per-thread partials (entry i in
+// slot i mod 1024, entries of one slot in index order, zeros adding nothing), block_sum and block_argmax are the same
+// device functions, and the Philox variates are drawn by token id.  Without a list (pl == NULL, or the row was not
+// produced in list mode) it runs resample_body's dense passes.
+__global__ __launch_bounds__(NT) void accept_resample_kernel(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
+                                                            long ld, int V, int32_t *__restrict__ seq, int L, int gamma,
+                                                            const float *__restrict__ r, uint64_t seed, uint64_t draw_scan,
+                                                            uint64_t draw_res, sd_accept_result *__restrict__ res,
+                                                            const int *__restrict__ err_flags, int n_err, int dt,
+                                                            const CandList *__restrict__ pl) {
+    __shared__ SampleShared S;
+    __shared__ float red[16];
+    __shared__ float part[NT];
+    __shared__ int cidx[SD_CL_CAP];
+    __shared__ float cval[SD_CL_CAP];
+    const int tid = threadIdx.x;
+    if (tid < 64) accept_scan_body(p_hist, q_hist, ld, seq, L, gamma, r, seed, draw_scan, res);
+    __syncthreads();
+    const int n = res->n, first = res->n_accepted;
+    const bool rejected = first < gamma;
+    const int nc = pl ? pl[first].n : -1;
+    if (nc < 0) {                                                 // no list for this row: the dense passes
+        resample_body(p_hist, q_hist, ld, V, seq, gamma, nullptr, seed, draw_res, res, nullptr, err_flags, n_err, dt);
+        return;
+    }
+    const CandList &cl = pl[first];
+    const float *q = q_hist + (size_t)n * ld;
+    const bool mine = tid < nc;
+    const int idx = mine ? cl.idx[tid] : 0;
+    const float pv = mine ? cl.prob[tid] : 0.f;
+    if (mine) cidx[tid] = idx;
+    // sum_i v_i over the row as resample_body's strided loop + block_sum computes it (v = 0 off the list)
+    auto row_sum = [&](float v) -> float {
+        part[tid] = 0.f;
+        if (mine) cval[tid] = v;
+        __syncthreads();
+        if (mine) {
+            const int slot = idx & (NT - 1);
+            int same = 0, before = 0;
+            for (int j = 0; j < nc; ++j) {
+                const int ij = cidx[j];
+                if (j != tid && (ij & (NT - 1)) == slot) { ++same; before += (ij < idx); }
+            }
+            if (same == 0) part[slot] = v;
+            else if (before == 0) {                               // lowest index of a slot shared by several entries: add them in index order
+                float acc = 0.f;
+                int last = -1;
+                for (int t = 0; t <= same; ++t) {
+                    int best = 0x7fffffff, bj = -1;
+                    for (int j = 0; j < nc; ++j) {
+                        const int ij = cidx[j];
+                        if ((ij & (NT - 1)) == slot && ij > last && ij < best) { best = ij; bj = j; }
+                    }
+                    acc += cval[bj];
+                    last = best;
+                }
+                part[slot] = acc;
+            }
+        }
+        __syncthreads();
+        return block_sum(part[tid], red);
+    };
+    // sample_core over weights that are zero off the list
+    auto sparse_sample = [&](float w, int *status) -> int {
+        int bad = mine && (!(w >= 0.0f) || w == INFINITY), pos = mine && w > 0.0f;
+        bad = block_sum_i(bad, S.redi);
+        pos = block_sum_i(pos, S.redi);
+        if (bad) { *status = 1; return 0; }
+        if (!pos) { *status = 2; return 0; }
+        ArgMax br = {0.f, 0x7fffffff}, bw = {0.f, 0x7fffffff};
+        if (mine) {
+            if (w > 0.0f) br = {rnd_dt(w / philox_exp(seed, draw_res, idx), dt), idx};
+            bw = {w, idx};
+            cval[tid] = w;
+        }
+        br = block_argmax(br, S.reda);
+        bw = block_argmax(bw, S.reda);                            // (its barriers also publish cval)
+        *status = 0;
+        // every ratio zero (underflow): the dense arg-max keeps its first element, token 0
+        int tok = (br.i == 0x7fffffff || !(br.v > 0.0f)) ? 0 : br.i;
+        float wtok = 0.f;
+        for (int j = 0; j < nc; ++j)
+            if (cidx[j] == tok) wtok = cval[j];
+        if (wtok < 1e-9f) tok = bw.i;                             // utils.py:228-230
+        return tok;
+    };
+    int status = 0, tok = 0, flags = 0;
+    if (rejected) {
+        const float d = mine ? rnd_dt(pv - q[idx], dt) : 0.f;
+        const float u = d > 0.f ? d : 0.f;
+        const float denom = max_fn_denom(row_sum(u), dt);         // max_fn, utils.py:236-245
+        tok = sparse_sample(mine ? rnd_dt(u / denom, dt) : 0.f, &status);
+        if (status != 0) {                                        // residual sample raised -> sample(max_fn(p_n)) (:2009-2010)
+            flags |= 1;
+            __syncthreads();
+            const float u2 = pv > 0.f ? pv : 0.f;
+            const float denom2 = max_fn_denom(row_sum(u2), dt);
+            tok = sparse_sample(mine ? rnd_dt(u2 / denom2, dt) : 0.f, &status);
+        }
+    } else {
+        tok = sparse_sample(pv, &status);                         // bonus token from p_last (:2019)
+    }
+    if (tid == 0) {
+        if (status != 0) flags |= 2;
+        for (int i = 0; i < n_err; ++i)                           // norm / sample error words of this iteration
+            if (err_flags[i]) flags |= 8;
+        res->flags |= flags;
+        res->next_token = status == 0 ? tok : -1;
+        if (status == 0) seq[n + 1] = tok;
+    }
+}
+
+// internal (sd_spec_iteration): accept scan + resample with the iteration's error words, target-row candidate lists or NULL
+int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
+                       const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
+                       sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode, const void *target_lists,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(accept_resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, L, gamma, r, philox_seed,
+                       draw_scan, draw_resample, res, err_flags, n_err, mode_dt(dtype_mode),
+                       static_cast<const CandList *>(target_lists));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }
