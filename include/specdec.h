@@ -344,6 +344,20 @@ int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_len, uint64_
                       uint64_t seed_accept, uint64_t draw_scan0, uint64_t draw_resample, const float *r_const,
                       sd_accept_result *res_host, int32_t *tok_host /* gamma+2 ids from seq[L], may be NULL */,
                       void *stream);
+/* The whole loop of speculative_sampling.py:1934-2046 for the device-RNG mode: iterations (sd_spec_iteration + one stream
+ * wait each) until the sequence holds T tokens, a new EOS appears (more than ori_eos_cnt of them in total) or an error
+ * word is set - no Python between iterations.  host_seq (host int32, capacity >= T + gamma + 1) holds the *len_io tokens so
+ * far and receives the new ones; *seed_io / *draw_io are the Philox stream position (advanced exactly as the iteration's
+ * draw order prescribes: gamma draft draws, the discarded target sample, gamma uniforms - or, with random_seed != 0, the
+ * stream restarted at (random_seed, 0) - and the resample); *draft_len_io / *target_len_io the cache lengths.  Per
+ * iteration i < *n_iters_out: acc_len_out[i]; p_at_out / q_at_out[i * gamma ..] (the accept ratios' operands);
+ * draft_ms_out / target_ms_out[i] when timing is on (else untouched; any of the five may be NULL).  *err_out: 0, or
+ * 1 = 'prob error' (sample / resample), 2 = 'norm logits error'.  res_host: pinned host memory for the result block. */
+int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int T, int eos_token_id, int ori_eos_cnt,
+                     uint64_t *seed_io, uint64_t *draw_io, uint64_t random_seed, const float *r_const, int *draft_len_io,
+                     int *target_len_io, sd_accept_result *res_host, int max_iters, int32_t *acc_len_out, float *p_at_out,
+                     float *q_at_out, float *draft_ms_out, float *target_ms_out, int *n_iters_out, int *err_out,
+                     void *stream);
 /* HIP-event timing of the draft phase and the target (verify) phase of the last iteration, on the launch stream. */
 int sd_spec_timing(sd_spec *sp, int on);
 int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms);

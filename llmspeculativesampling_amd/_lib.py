@@ -104,6 +104,8 @@ SYMBOLS = [
     ("sd_session_forward_tree", _I, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), _I, _I, _VP, _L, _VP]),
     ("sd_session_compact_kv", _I, [_VP, _I, _VP, _I, _VP]),
     ("sd_session_chain_status", _I, [_VP, _VP]),
+    ("sd_spec_generate", _I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, C.c_uint64, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP,
+                              _VP, _VP, _VP]),
     ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),
     ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
     ("sd_spec_destroy", _I, [_VP]),

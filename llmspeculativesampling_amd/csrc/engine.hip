@@ -134,14 +134,30 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // ---- split-K policy.  A workgroup (4 waves) owns one n-tile x one k-slab and folds its waves in LDS, so
 // SB slabs reach HBM.  SB is chosen so that about `target` workgroups exist (>= 4 per CU), with at least
 // 8 k-steps (8 KiB of weights) per workgroup.
+// Environment tunables, sampled when a session (or a spec handle) is created and by the public one-off GEMM entries - not
+// per launch: a draft step is ~40 getenv() scans otherwise, on the host thread that has to keep the GPU fed.
+struct EnvTun {
+    int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
+};
+static EnvTun g_env;
+static void refresh_env() {
+    auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    g_env.gemm_ntw = geti("SD_GEMM_NTW", 4);
+    g_env.gemm_units = geti("SD_GEMM_UNITS", -1);
+    g_env.small_path = geti("SD_SMALL_PATH", 0);      // off by default: measured slower than the per-op chain
+    g_env.small_split_bytes = geti("SD_SMALL_SPLIT_BYTES", 0);
+    g_env.chain = geti("SD_CHAIN", 0);                // 1: in-order chained launch, 2: persistent engine (both measured slower)
+    g_env.fuse_embed_qkv = geti("SD_FUSE_EMBED_QKV", 1);
+    g_env.head_tiles = geti("SD_HEAD_TILES", 1);
+}
+
 static int gemm_ntw(int N, int M) {
     if (M <= 16) return 1;
     const int ntl = N / 16;
     // n-tiles per wave: more of them amortise the activation fragment loads, fewer give more workgroups.  Stream-batched
     // decode, 4 / 6 / 8 / 10 streams x 5 rows (bench.py --batch-streams): 529 / 727 / 861 / 990 tok/s with 4 tiles,
     // 504 / 753 / 808 / 908 with 2; 8 tiles: register pressure, slower everywhere.
-    const char *env = getenv("SD_GEMM_NTW");
-    const int want = env ? atoi(env) : 4;
+    const int want = g_env.gemm_ntw;
     if (want >= 8 && ntl % 8 == 0) return 8;
     if (want >= 4 && ntl % 4 == 0) return 4;
     if (want >= 2 && ntl % 2 == 0) return 2;
@@ -153,9 +169,8 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
     int max_s = KS / 8;
     if (max_s < 1) max_s = 1;
     int S = 1;
-    const char *env = getenv("SD_GEMM_UNITS");
-    if (env) {
-        S = (atoi(env) + NTL / 2) / NTL;
+    if (g_env.gemm_units >= 0) {
+        S = (g_env.gemm_units + NTL / 2) / NTL;
     } else if (M > 16) {
         // many rows: every extra slab costs a write + a read of Mpad*N floats, which at 64 rows rivals the weight bytes
         // (256*S/K of them), so take the S that minimises (weights + slab traffic) / CU-fill efficiency
@@ -303,6 +318,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
 // (or the model is fp32, whose simple GEMM has no row limit), else the streaming kernel's 64.
 extern "C" int sd_model_max_rows(const sd_model *m) {
     if (!m) return 0;
+    refresh_env();
     const sd_model_config &c = m->cfg;
     if (!is16(c.dtype)) return SD_MAX_FWD_ROWS;
     const int ed = embed_dim(c);
@@ -314,6 +330,7 @@ extern "C" int sd_model_max_rows(const sd_model *m) {
 }
 
 extern "C" size_t sd_session_scratch_bytes(const sd_model *m, int max_rows) {
+    refresh_env();
     return plan_scratch(m->cfg, std::min(max_rows, sd_model_max_rows(m))).total;
 }
 
@@ -325,6 +342,7 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
         SD_REQUIRE(max_seq <= m->cfg.max_pos, "sd_session_create: OPT is limited to %d positions", m->cfg.max_pos);
     else
         SD_REQUIRE(max_seq <= m->cfg.max_pos, "sd_session_create: rope table has %d rows, max_seq %d", m->cfg.max_pos, max_seq);
+    refresh_env();
     sd_session *s = new sd_session();
     s->m = m;
     s->max_seq = max_seq;
@@ -758,8 +776,7 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
 // ---- small-model decode path (small_kernels.h): 5 launches per layer + the head --------------------------------
 static bool small_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
-    const char *env = getenv("SD_SMALL_PATH");                         // (read per call: the tests flip it in-process)
-    const int enabled = env ? atoi(env) : 0;      // off by default: measured slower than the per-op chain
+    const int enabled = g_env.small_path;
     if (!enabled || c.dtype != SD_BF16 || !c.fused_layout || tab.contig || s->tp) return false;
     if (tab.n_rows > SMALL_MAX_ROWS || tab.n_logit_rows > SMALL_MAX_ROWS) return false;
     if (c.hidden > 2048 || c.hidden % 32 != 0 || embed_dim(c) != c.hidden) return false;
@@ -771,8 +788,7 @@ static bool small_path_ok(const sd_session *s, const RowTab &tab) {
 // k-slabs of the small path's O / down GEMMs.  Default: the streaming GEMM's own policy (bit-identical slabs, what the
 // parity tests compare against); SD_SMALL_SPLIT_BYTES = b cuts them so that a workgroup streams about b bytes.
 static void small_split(int N, int K, int *S_out, int *ksp_out) {
-    const char *env = getenv("SD_SMALL_SPLIT_BYTES");
-    const int bytes = env ? atoi(env) : 0;
+    const int bytes = g_env.small_split_bytes;
     const int KS = K / 32;
     if (bytes <= 0) { gemm_split(N, K, 1, S_out, ksp_out); }
     else {
@@ -909,8 +925,7 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
 // The per-op path's plans (split counts, workgroup shapes) are kept, so both routes give identical bits.
 static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
-    const char *env = getenv("SD_CHAIN");                              // (read per call: the tests flip it in-process)
-    const int enabled = env ? atoi(env) : 0;                           // 1: in-order chained launch, 2: persistent engine
+    const int enabled = g_env.chain;                                   // 1: in-order chained launch, 2: persistent engine
     if (!enabled || !is16(c.dtype) || !c.fused_layout || tab.contig || s->tp) return false;
     if (tab.n_rows > 16 || c.hidden % 32 != 0 || c.hidden < 1024) return false;
     if (c.arch == SD_ARCH_OPT && (!c.opt_pre_ln || embed_dim(c) != c.hidden)) return false;
@@ -929,7 +944,7 @@ static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
     }
     return true;
 }
-static int chain_mode() { const char *env = getenv("SD_CHAIN"); return env ? atoi(env) : 0; }
+static int chain_mode() { return g_env.chain; }
 
 template <typename H>
 static int launch_chain(sd_session *s, const RowTab &tab, int l, int rn_threads, unsigned epoch, hipStream_t st) {
@@ -1035,8 +1050,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
     // launch instead of two, 6.7 us against 5.0 + 5.0 on llama-68m (tools/draft_step_bench.py)
     bool qkv0_done = false;
     if constexpr (std::is_same<T, bf16_t>::value) {
-        const char *env = getenv("SD_FUSE_EMBED_QKV");
-        if ((env ? atoi(env) : 1) && fused && pre && (llama || ED == H) && !tab.contig && n_new <= SMALL_MAX_ROWS && H <= 2048 &&
+        if (g_env.fuse_embed_qkv && fused && pre && (llama || ED == H) && !tab.contig && n_new <= SMALL_MAX_ROWS && H <= 2048 &&
             H % 32 == 0 && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
             GemmEpi e = {};
             e.out = (bf16_t *)qb; e.bias = (const bf16_t *)m->bqkv[0];
@@ -1446,6 +1460,7 @@ extern "C" int sd_pack_activation_bf16(const void *x_rowmajor, void *x_tiled, in
 extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, int M, int N, int K, float *part,
                             size_t part_floats, float *out, int *splits_out, void *stream) {
     SD_REQUIRE(w_packed && x && part, "sd_gemm_bf16: null argument");
+    refresh_env();
     SD_REQUIRE(M >= 1 && M <= SD_MAX_FWD_ROWS && N % 16 == 0 && K % 32 == 0,
                "sd_gemm_bf16: need 1<=M<=%d, N%%16==0, K%%32==0", SD_MAX_FWD_ROWS);
     const GemmPlan pl = gemm_plan(N, K, M, x_tiled != 0);
@@ -1508,6 +1523,7 @@ struct sd_spec {
     sd_accept_result *res_dev;
     void *norm_ws;               // sd_norm_workspace_bytes(gamma+1) bytes, may be NULL
     hipEvent_t ev[4];
+    hipEvent_t ev_done;          // end of an iteration's device -> host copy (sd_spec_generate polls it)
     int timing;
 };
 
@@ -1520,12 +1536,14 @@ extern "C" int sd_spec_create(sd_session *draft, sd_session *target, int gamma, 
     SD_REQUIRE(gamma >= 1 && gamma <= 16, "sd_spec_create: gamma must be in 1..16");
     SD_REQUIRE(draft->m->cfg.vocab == target->m->cfg.vocab, "sd_spec_create: draft and target vocabularies differ");
     SD_REQUIRE(temperature != 0.0f, "sd_spec_create: temperature must be non-zero");
+    refresh_env();
     sd_spec *sp = new sd_spec();
     sp->draft = draft; sp->target = target; sp->gamma = gamma; sp->temperature = temperature; sp->top_k = top_k;
     sp->top_p = top_p; sp->V = draft->m->cfg.vocab; sp->seq = seq; sp->q_hist = q_hist; sp->p_hist = p_hist; sp->ld = ld;
     sp->draft_logits = draft_logits; sp->ld_dl = ld_draft_logits; sp->target_logits = target_logits; sp->ld_tl = ld_target_logits;
     sp->err = err_words; sp->res_dev = res_dev; sp->norm_ws = norm_workspace; sp->timing = 0;
     for (int i = 0; i < 4; ++i) SD_HIP_CHECK(hipEventCreate(&sp->ev[i]));
+    SD_HIP_CHECK(hipEventCreateWithFlags(&sp->ev_done, hipEventDisableTiming));
     *out = sp;
     return SD_OK;
 }
@@ -1533,6 +1551,7 @@ extern "C" int sd_spec_create(sd_session *draft, sd_session *target, int gamma, 
 extern "C" int sd_spec_destroy(sd_spec *sp) {
     if (!sp) return SD_OK;
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(sp->ev[i]);
+    (void)hipEventDestroy(sp->ev_done);
     delete sp;
     return SD_OK;
 }
@@ -1603,7 +1622,7 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     int rc;
     // EPI_HEAD's tile maxima serve the top-k candidate search only (1 <= k <= 64, positive temperature, 16 | V >= 4096)
     const bool tiles_ok = sp->top_k >= 1 && sp->top_k <= 64 && sp->temperature > 0.0f && V % 16 == 0 && V >= 4096 &&
-                          V <= 65536 && sp->ld % 4 == 0 && (getenv("SD_HEAD_TILES") ? atoi(getenv("SD_HEAD_TILES")) : 1);
+                          V <= 65536 && sp->ld % 4 == 0 && g_env.head_tiles;
     if (sp->timing) SD_HIP_CHECK(hipEventRecord(sp->ev[0], st));
     // ---- draft: gamma steps; the sampled token goes straight into seq[] where the next step's embed reads it
     for (int i = 0; i < g; ++i) {
@@ -1666,4 +1685,75 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     if (tok_host)       // optional second copy; the result block already carries the drafted tokens and the next one
         SD_HIP_CHECK(hipMemcpyAsync(tok_host, sp->seq + L, sizeof(int32_t) * (size_t)(g + 2), hipMemcpyDeviceToHost, st));
     return SD_OK;
+}
+
+// The device-RNG loop without the interpreter between iterations (reference speculative_sampling.py:1934-2046).
+extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int T, int eos_token_id, int ori_eos_cnt,
+                                uint64_t *seed_io, uint64_t *draw_io, uint64_t random_seed, const float *r_const,
+                                int *draft_len_io, int *target_len_io, sd_accept_result *res_host, int max_iters,
+                                int32_t *acc_len_out, float *p_at_out, float *q_at_out, float *draft_ms_out,
+                                float *target_ms_out, int *n_iters_out, int *err_out, void *stream) {
+    SD_REQUIRE(sp && host_seq && len_io && seed_io && draw_io && draft_len_io && target_len_io && res_host && n_iters_out && err_out,
+               "sd_spec_generate: null argument");
+    SD_REQUIRE(!random_seed || r_const, "sd_spec_generate: random_seed needs its uniform (r_const)");
+    const int g = sp->gamma;
+    int len = *len_io, draft_len = *draft_len_io, target_len = *target_len_io, iters = 0, eos_total = ori_eos_cnt;
+    uint64_t seed = *seed_io, draw = *draw_io;
+    *err_out = 0;
+    int rc = SD_OK;
+    while (len < T && iters < max_iters) {
+        const int L = len;
+        const uint64_t d_draft = draw;                            // gamma draft samples, then the discarded target sample
+        draw += (uint64_t)g + 1;
+        const uint64_t seed_draft = seed;
+        uint64_t d_scan = 0;
+        if (random_seed) { seed = random_seed; draw = 0; }        // :1976-1977: the stream restarts before every uniform
+        else { d_scan = draw; draw += (uint64_t)g; }
+        const uint64_t d_res = draw++;
+        if ((rc = sd_spec_iteration(sp, L, draft_len, target_len, seed_draft, d_draft, seed, d_scan, d_res, r_const, res_host,
+                                    nullptr, stream)) != SD_OK)
+            break;
+        // wait for the result block by polling an event (a blocking wait parks the thread, and the launches of the next
+        // iteration's draft steps - which the GPU consumes as fast as they arrive - then start from a cold core)
+        SD_HIP_CHECK(hipEventRecord(sp->ev_done, (hipStream_t)stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(sp->ev_done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { sd_set_error("sd_spec_generate: %s", hipGetErrorString(q)); return SD_ERR_HIP; }
+        }
+        const sd_accept_result r = *res_host;
+        if (r.flags & 2) { *err_out = 1; break; }
+        if (r.flags & 8) {                                        // which word: a draft sample error, or a norm error
+            std::vector<int> ew(3 * g + 1);
+            SD_HIP_CHECK(hipMemcpy(ew.data(), sp->err, sizeof(int) * ew.size(), hipMemcpyDeviceToHost));
+            bool samp = false;
+            for (int i = g; i < 2 * g; ++i) samp = samp || ew[i] != 0;
+            *err_out = samp ? 1 : 2;
+            break;
+        }
+        if (sp->timing && (draft_ms_out || target_ms_out)) {
+            float dms = 0.f, tms = 0.f;
+            SD_HIP_CHECK(hipEventElapsedTime(&dms, sp->ev[0], sp->ev[1]));
+            SD_HIP_CHECK(hipEventElapsedTime(&tms, sp->ev[2], sp->ev[3]));
+            if (draft_ms_out) draft_ms_out[iters] = dms;
+            if (target_ms_out) target_ms_out[iters] = tms;
+        }
+        const int l = r.n_accepted, n = r.n;
+        if (acc_len_out) acc_len_out[iters] = l;
+        for (int i = 0; i < g; ++i) {
+            if (p_at_out) p_at_out[(size_t)iters * g + i] = r.p_at[i];
+            if (q_at_out) q_at_out[(size_t)iters * g + i] = r.q_at[i];
+        }
+        ++iters;
+        SD_REQUIRE(n >= L - 1 && l >= 0 && l <= g, "sd_spec_generate: inconsistent result block (n %d, L %d, accepted %d)", n, L, l);
+        for (int i = 0; i < l; ++i) host_seq[len++] = r.drafted[i];
+        host_seq[len++] = r.next_token;
+        draft_len = std::min(L + g - 1, n + 1);                   // rollback(n + 1) of both caches (:2000, :2015 / 2023)
+        target_len = n + 1;
+        for (int i = L; i < len; ++i) eos_total += host_seq[i] == eos_token_id;
+        if (eos_total > ori_eos_cnt) break;                       // the caller cuts after the first new EOS (:2033-2041)
+    }
+    *len_io = len; *draft_len_io = draft_len; *target_len_io = target_len;
+    *seed_io = seed; *draw_io = draw; *n_iters_out = iters;
+    return rc;
 }

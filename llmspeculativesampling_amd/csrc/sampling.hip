@@ -1113,6 +1113,7 @@ extern "C" int sd_philox_uniform(uint64_t seed, uint64_t draw_index, int n, floa
     return SD_OK;
 }
 
+int g_norm_tile_threads = 0;                 // (tools/norm_stamps.cpp sweeps it; 0 = SD_NORM_TILE_THREADS or 256)
 static int launch_norm(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, bool do_sample,
                        const float *noise, uint64_t seed, uint64_t draw, int *tok_out, int *samp_err, void *workspace,
@@ -1147,7 +1148,8 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
         SD_LAUNCH_CHECK();
     }
     // with tile maxima the work is a few dozen candidates: 4 waves (cheap barriers), no row staging
-    const int nthr = tile_max ? (getenv("SD_NORM_TILE_THREADS") ? atoi(getenv("SD_NORM_TILE_THREADS")) : 256) : NT;
+    static const int tile_threads_env = getenv("SD_NORM_TILE_THREADS") ? atoi(getenv("SD_NORM_TILE_THREADS")) : 256;
+    const int nthr = tile_max ? (g_norm_tile_threads > 0 ? g_norm_tile_threads : tile_threads_env) : NT;
     const int staged_k = tile_max ? 0 : staged;
     const size_t lds_k = tile_max ? base : lds;
     if (do_sample)

@@ -219,71 +219,67 @@ def _native_device_loop(prefix, draft, target, seq32, host_seq, ori_eos_cnt, eos
         g = torch.Generator().manual_seed(int(random_seed))
         r_const = torch.rand(1, generator=g).repeat(gamma).to(dev)
     st = _stream()
-    stream_obj = torch.cuda.current_stream()
     approx_time = target_time = other_time = 0
     calls = 0
     acc_rate, acc_len = [], []
-    out_tokens = host_seq
     draft_len = target_len = 0
-    res_view = res_host.numpy()
-    dms, tms = C.c_float(0), C.c_float(0)
-    eos_total = ori_eos_cnt
+    # the loop itself runs inside libspecdec (sd_spec_generate): one call, one stream wait per iteration in native code,
+    # the interpreter only sees the finished sequence and the per-iteration statistics
+    cap = T + gamma + 2
+    seq_host = np.zeros(cap, dtype=np.int32)
+    seq_host[:len(host_seq)] = host_seq
+    max_iters = max(1, T - len(host_seq))
+    acc_arr = np.zeros(max_iters, dtype=np.int32)
+    p_arr = np.zeros(max_iters * gamma, dtype=np.float32)
+    q_arr = np.ones(max_iters * gamma, dtype=np.float32)
+    dms_arr = np.zeros(max_iters, dtype=np.float32)
+    tms_arr = np.zeros(max_iters, dtype=np.float32)
+    c_len, c_dl, c_tl = C.c_int(len(host_seq)), C.c_int(0), C.c_int(0)
+    c_seed, c_draw = C.c_uint64(noise.seed), C.c_uint64(noise.draw)
+    c_iters, c_err = C.c_int(0), C.c_int(0)
+    out_tokens = host_seq
     try:
-        while len(host_seq) < T:
-            tick = process_time_ns()
-            L = len(host_seq)
-            d_draft = noise.next_draws(gamma)
-            noise.next_draws(1)                          # the discarded target sample still advances the stream
-            seed_draft = noise.seed
-            if random_seed:
-                noise.reseed(random_seed)
-                d_scan = 0
-            else:
-                d_scan = noise.next_draws(gamma)
-            d_res = noise.next_draws(1)
-            check(lib.sd_spec_iteration(sp, L, draft_len, target_len, seed_draft, d_draft, noise.seed, d_scan, d_res,
-                                        r_const.data_ptr() if r_const is not None else None, res_host.data_ptr(),
-                                        None, st), "sd_spec_iteration")
-            stream_obj.synchronize()
-            res = SdAcceptResult.from_buffer_copy(res_view.tobytes())
-            if res.flags & 2:
-                raise RuntimeError("prob error")
-            if res.flags & 8:
-                if bool(err_words[gamma:2 * gamma].any()):
-                    raise RuntimeError("prob error")
-                raise RuntimeError("norm logits error")
-            if timed:
-                # the reference's approx_time / target_time are host process_time deltas around generate() (:1937-1962);
-                # here the host only enqueues, so the device time of the two phases (HIP events) is what is reported
-                check(lib.sd_spec_last_times(sp, C.byref(dms), C.byref(tms)), "sd_spec_last_times")
-                approx_time += int(dms.value * 1e6)
-                target_time += int(tms.value * 1e6)
-                if timing_log is not None:
-                    timing_log["draft_ms"].append(dms.value)
-                    timing_log["target"].append((tms.value, L + gamma - target_len, L + gamma))
-            calls += 1
-            l, n, t = res.n_accepted, res.n, res.next_token
-            for i in range(gamma):
-                acc_rate.append(min(1.0, float(res.p_at[i]) / float(res.q_at[i])))
-            acc_len.append(l)
-            assert n >= L - 1, f"n {n}, prefix_len {L}"
-            new_toks = [int(res.drafted[i]) for i in range(l)] + [t]      # the result block carries the drafted ids
-            host_seq = host_seq + new_toks
-            draft_len = min(L + gamma - 1, n + 1)        # rollback(n+1) of both caches (:2000, :2015/2023)
-            target_len = n + 1
-            out_tokens = host_seq
-            eos_total += sum(1 for x in new_toks if x == eos_token_id)      # running count: the loop stays O(new tokens)
-            if eos_total > ori_eos_cnt:
-                seen, cut = 0, len(host_seq)
-                for idx, x in enumerate(host_seq):
-                    if x == eos_token_id:
-                        seen += 1
-                        if seen == ori_eos_cnt + 1:
-                            cut = idx + 1
-                            break
-                out_tokens = host_seq[:cut]
-                break
-            other_time += process_time_ns() - tick       # host CPU time of the iteration (enqueue + wait + bookkeeping)
+        tick = process_time_ns()
+        check(lib.sd_spec_generate(sp, seq_host.ctypes.data, C.byref(c_len), T, int(eos_token_id), int(ori_eos_cnt),
+                                   C.byref(c_seed), C.byref(c_draw), int(random_seed or 0),
+                                   r_const.data_ptr() if r_const is not None else None, C.byref(c_dl), C.byref(c_tl),
+                                   res_host.data_ptr(), max_iters, acc_arr.ctypes.data, p_arr.ctypes.data, q_arr.ctypes.data,
+                                   dms_arr.ctypes.data if timed else None, tms_arr.ctypes.data if timed else None,
+                                   C.byref(c_iters), C.byref(c_err), st), "sd_spec_generate")
+        other_time += process_time_ns() - tick           # host CPU time of the loop (enqueue + waits + bookkeeping)
+        noise.seed, noise.draw = c_seed.value, c_draw.value
+        if c_err.value == 1:
+            raise RuntimeError("prob error")
+        if c_err.value == 2:
+            raise RuntimeError("norm logits error")
+        calls = c_iters.value
+        draft_len, target_len = c_dl.value, c_tl.value
+        host_seq = seq_host[:c_len.value].tolist()
+        acc_len = acc_arr[:calls].tolist()
+        # python double ratio of the two float32 values, as the reference's .item() division (:1966-1971)
+        acc_rate = np.minimum(1.0, p_arr[:calls * gamma].astype(np.float64) / q_arr[:calls * gamma].astype(np.float64)).tolist()
+        if timed:
+            # the reference's approx_time / target_time are host process_time deltas around generate() (:1937-1962);
+            # here the host only enqueues, so the device time of the two phases (HIP events) is what is reported
+            approx_time = int(sum(int(v * 1e6) for v in dms_arr[:calls]))
+            target_time = int(sum(int(v * 1e6) for v in tms_arr[:calls]))
+            if timing_log is not None:
+                Lc, tl = seq_len0, 0
+                for i in range(calls):
+                    timing_log["draft_ms"].append(float(dms_arr[i]))
+                    timing_log["target"].append((float(tms_arr[i]), Lc + gamma - tl, Lc + gamma))
+                    tl = Lc + int(acc_arr[i])                    # n + 1 with n = L + l - 1
+                    Lc += int(acc_arr[i]) + 1
+        out_tokens = host_seq
+        if sum(1 for x in host_seq if x == eos_token_id) > ori_eos_cnt:
+            seen, cut = 0, len(host_seq)
+            for idx, x in enumerate(host_seq):
+                if x == eos_token_id:
+                    seen += 1
+                    if seen == ori_eos_cnt + 1:
+                        cut = idx + 1
+                        break
+            out_tokens = host_seq[:cut]
     except Exception as e:
         print(e)
         lib.sd_spec_destroy(sp)

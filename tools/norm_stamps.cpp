@@ -32,10 +32,10 @@ int main() {
     }
     int ref; hipMemcpy(&ref, tok, 4, hipMemcpyDeviceToHost);
     for (const char *thr : {"1024", "512", "256", "128"}) {
-        setenv("SD_NORM_TILE_THREADS", thr, 1);
+        g_norm_tile_threads = atoi(thr);
         for (int it = 0; it < 3; ++it) {
             hipMemset(o, 0, V * 4);
-            sd_norm_rows_with_tiles(x, 1, V, V, 1.0f, 20, 0.9f, 0, o, V, err, 1, 2, tok, err + 1, nullptr, tm, nullptr);
+            sd_norm_rows_with_tiles(x, 1, V, V, 1.0f, 20, 0.9f, 0, o, V, err, 1, 2, tok, err + 1, nullptr, tm, nullptr, nullptr);
             hipDeviceSynchronize();
         }
         char tag[64]; int t2; hipMemcpy(&t2, tok, 4, hipMemcpyDeviceToHost);
