@@ -358,6 +358,35 @@ int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int T, int eos
                      int *target_len_io, sd_accept_result *res_host, int max_iters, int32_t *acc_len_out, float *p_at_out,
                      float *q_at_out, float *draft_ms_out, float *target_ms_out, int *n_iters_out, int *err_out,
                      void *stream);
+/* The stream-batched loop (throughput mode) without the interpreter between iterations: up to 16
+ * independent streams decode in lock-step - every draft step one sd_batch_forward + sd_norm_batch over the active
+ * streams, every verify one target pass per max_rows_per_forward / (gamma + 1) streams, then sd_accept_batch, one copy of
+ * the result blocks and one wait - until every stream holds T tokens or has produced a new EOS.  Per stream: the two
+ * sessions, the device token buffer / probability arenas / error words, its device and pinned-host result block (the
+ * streams' blocks must be consecutive: one copy moves them all), the host token buffer and the in/out loop state
+ * (lengths, cache lengths, Philox position); per-iteration statistics as in sd_spec_generate.  Each stream runs exactly
+ * the algorithm of sd_spec_generate with its own Philox stream.  verify_ms_out / verify_streams_out / verify_ctx_out
+ * (host, max_iters_log entries, may be NULL): time of each iteration's verify passes, streams in it, their mean context.
+ * *err_out: 1 when a stream hit a sampling / normalisation error (the reference raises). */
+typedef struct {
+    sd_session *draft, *target;
+    int32_t *seq;
+    float *q_hist, *p_hist;
+    int *err_words;
+    sd_accept_result *res_dev, *res_host;
+    int32_t *host_seq;
+    int32_t len, T, ori_eos_cnt, draft_len, target_len;
+    uint64_t seed, draw;
+    int32_t done, calls;
+    int32_t *acc_len_out;
+    float *p_at_out, *q_at_out;
+} sd_batch_stream;
+int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, int gamma, float temperature, int top_k, float top_p,
+                           int V, long ld, int eos_token_id, uint64_t random_seed, const float *r_const,
+                           int draft_norm_mode, int target_norm_mode, float *draft_logits, long ld_draft_logits,
+                           float *target_logits, long ld_target_logits, void *norm_workspace, int max_rows_per_forward,
+                           float *verify_ms_out, int32_t *verify_streams_out, float *verify_ctx_out, int max_iters_log,
+                           int *n_iters_out, int *err_out, void *stream);
 /* HIP-event timing of the draft phase and the target (verify) phase of the last iteration, on the launch stream. */
 int sd_spec_timing(sd_spec *sp, int on);
 int sd_spec_last_times(sd_spec *sp, float *draft_ms, float *target_ms);

@@ -45,6 +45,15 @@ class SdMultiItem(C.Structure):
     _fields_ = [("p_hist", C.c_void_p), ("q_hist", C.c_void_p), ("seq", C.c_void_p)]
 
 
+class SdBatchStream(C.Structure):
+    _fields_ = [("draft", C.c_void_p), ("target", C.c_void_p), ("seq", C.c_void_p), ("q_hist", C.c_void_p),
+                ("p_hist", C.c_void_p), ("err_words", C.c_void_p), ("res_dev", C.c_void_p), ("res_host", C.c_void_p),
+                ("host_seq", C.c_void_p), ("len", C.c_int32), ("T", C.c_int32), ("ori_eos_cnt", C.c_int32),
+                ("draft_len", C.c_int32), ("target_len", C.c_int32), ("seed", C.c_uint64), ("draw", C.c_uint64),
+                ("done", C.c_int32), ("calls", C.c_int32), ("acc_len_out", C.c_void_p), ("p_at_out", C.c_void_p),
+                ("q_at_out", C.c_void_p)]
+
+
 class SdBatchItem(C.Structure):
     _fields_ = [("session", C.c_void_p), ("seq", C.c_void_p), ("pos0", C.c_int32), ("n_new", C.c_int32),
                 ("n_logits", C.c_int32)]
@@ -104,6 +113,8 @@ SYMBOLS = [
     ("sd_session_forward_tree", _I, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), _I, _I, _VP, _L, _VP]),
     ("sd_session_compact_kv", _I, [_VP, _I, _VP, _I, _VP]),
     ("sd_session_chain_status", _I, [_VP, _VP]),
+    ("sd_spec_batch_generate", _I, [_VP, _I, _I, C.c_float, _I, C.c_float, _I, C.c_long, _I, C.c_uint64, _VP, _I, _I, _VP,
+                                    C.c_long, _VP, C.c_long, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     ("sd_spec_generate", _I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, C.c_uint64, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP, _VP]),
     ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),

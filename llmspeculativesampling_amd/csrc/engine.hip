@@ -1757,3 +1757,156 @@ extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int
     *seed_io = seed; *draw_io = draw; *n_iters_out = iters;
     return rc;
 }
+
+// The stream-batched loop of sampling/batch.py in native code (reference algorithm per stream: speculative_sampling.py:1934-2046).
+extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, int gamma, float temperature, int top_k,
+                                      float top_p, int V, long ld, int eos_token_id, uint64_t random_seed,
+                                      const float *r_const, int draft_norm_mode, int target_norm_mode, float *draft_logits,
+                                      long ld_draft_logits, float *target_logits, long ld_target_logits,
+                                      void *norm_workspace, int max_rows_per_forward, float *verify_ms_out,
+                                      int32_t *verify_streams_out, float *verify_ctx_out, int max_iters_log,
+                                      int *n_iters_out, int *err_out, void *stream) {
+    SD_REQUIRE(streams && n_streams >= 1 && n_streams <= 16 && gamma >= 1 && gamma <= 16 && draft_logits && target_logits &&
+               n_iters_out && err_out, "sd_spec_batch_generate: bad arguments");
+    SD_REQUIRE(!random_seed || r_const, "sd_spec_batch_generate: random_seed needs its uniform (r_const)");
+    for (int i = 1; i < n_streams; ++i)
+        SD_REQUIRE(streams[i].res_dev == streams[0].res_dev + i && streams[i].res_host == streams[0].res_host + i,
+                   "sd_spec_batch_generate: the streams' result blocks must be consecutive");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = gamma, n_err = 3 * g + 1;
+    const int max_verify = std::max(1, max_rows_per_forward / (g + 1));        // streams per target pass
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    SD_HIP_CHECK(hipEventCreate(&ev0));
+    SD_HIP_CHECK(hipEventCreate(&ev1));
+    SD_HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    *err_out = 0;
+    int iters = 0, rc = SD_OK;
+    std::vector<sd_batch_stream *> act;
+    std::vector<int> Ls;
+    std::vector<uint64_t> base_draw;
+    std::vector<sd_batch_item> items;
+    std::vector<sd_norm_row> rows;
+    std::vector<sd_accept_item> aitems;
+    for (int i = 0; i < n_streams; ++i) { streams[i].done = 0; streams[i].calls = 0; }
+    for (;;) {
+        act.clear();
+        for (int i = 0; i < n_streams; ++i) {
+            sd_batch_stream &s = streams[i];
+            if (!s.done && s.len >= s.T) s.done = 1;
+            if (!s.done) act.push_back(&s);
+        }
+        if (act.empty()) break;
+        const int n = (int)act.size();
+        Ls.assign(n, 0);
+        base_draw.assign(n, 0);
+        double ctx = 0.0;
+        for (int j = 0; j < n; ++j) {
+            Ls[j] = act[j]->len;
+            base_draw[j] = act[j]->draw;
+            act[j]->draw += (uint64_t)g;
+            ctx += Ls[j];
+        }
+        // ---- draft: gamma steps over all active streams
+        for (int i = 0; i < g && rc == SD_OK; ++i) {
+            items.assign(n, sd_batch_item{});
+            rows.assign(n, sd_norm_row{});
+            for (int j = 0; j < n; ++j) {
+                sd_batch_stream &s = *act[j];
+                items[j].session = s.draft; items[j].seq = s.seq; items[j].pos0 = s.draft_len;
+                items[j].n_new = Ls[j] + i - s.draft_len; items[j].n_logits = 1;
+                rows[j].probs_out = s.q_hist + (size_t)(Ls[j] + i - 1) * ld;
+                rows[j].err = s.err_words + i;
+                rows[j].exp_noise = nullptr;
+                rows[j].philox_seed = s.seed;
+                rows[j].draw_index = base_draw[j] + (uint64_t)i;
+                rows[j].tok_out = s.seq + (Ls[j] + i);
+                rows[j].sample_err = s.err_words + g + i;
+                s.draft_len = Ls[j] + i;
+            }
+            if ((rc = sd_batch_forward(items.data(), n, draft_logits, ld_draft_logits, stream)) != SD_OK) break;
+            rc = sd_norm_batch(draft_logits, n, V, ld_draft_logits, temperature, top_k, top_p, draft_norm_mode, rows.data(), 1,
+                               norm_workspace, stream);
+        }
+        if (rc != SD_OK) break;
+        // ---- verify: the uncached rows of every stream, max_verify streams per pass over the target weights
+        SD_HIP_CHECK(hipEventRecord(ev0, st));
+        for (int a0 = 0; a0 < n && rc == SD_OK; a0 += max_verify) {
+            const int m = std::min(max_verify, n - a0);
+            items.assign(m, sd_batch_item{});
+            rows.clear();
+            for (int j = 0; j < m; ++j) {
+                sd_batch_stream &s = *act[a0 + j];
+                const int L = Ls[a0 + j], nn = L + g - s.target_len;
+                items[j].session = s.target; items[j].seq = s.seq; items[j].pos0 = s.target_len;
+                items[j].n_new = nn; items[j].n_logits = nn;
+                for (int r = 0; r < nn; ++r) {
+                    sd_norm_row row = {};
+                    row.probs_out = s.p_hist + (size_t)(L + g - nn + r) * ld;
+                    row.err = s.err_words + 2 * g + std::min(r, g);
+                    rows.push_back(row);
+                }
+            }
+            if ((rc = sd_batch_forward(items.data(), m, target_logits, ld_target_logits, stream)) != SD_OK) break;
+            rc = sd_norm_batch(target_logits, (int)rows.size(), V, ld_target_logits, temperature, top_k, top_p, target_norm_mode,
+                               rows.data(), 0, norm_workspace, stream);
+        }
+        if (rc != SD_OK) break;
+        SD_HIP_CHECK(hipEventRecord(ev1, st));
+        // ---- accept scan + residual / bonus sample, all streams in two launches
+        aitems.assign(n, sd_accept_item{});
+        for (int j = 0; j < n; ++j) {
+            sd_batch_stream &s = *act[j];
+            s.draw += 1;                                          // the discarded target sample
+            uint64_t d_scan = 0;
+            if (random_seed) { s.seed = random_seed; s.draw = 0; }
+            else { d_scan = s.draw; s.draw += (uint64_t)g; }
+            sd_accept_item &it = aitems[j];
+            it.p_hist = s.p_hist; it.q_hist = s.q_hist; it.seq = s.seq; it.L = Ls[j];
+            it.r = r_const; it.exp_noise = nullptr;
+            it.philox_seed = s.seed; it.draw_scan = d_scan; it.draw_resample = s.draw++;
+            it.res = s.res_dev; it.err_flags = s.err_words; it.n_err = n_err;
+        }
+        const int res_mode = target_norm_mode == draft_norm_mode ? target_norm_mode : 0;
+        if ((rc = sd_accept_batch(aitems.data(), n, ld, V, g, res_mode, stream)) != SD_OK) break;
+        SD_HIP_CHECK(hipMemcpyAsync(streams[0].res_host, streams[0].res_dev, sizeof(sd_accept_result) * (size_t)n_streams,
+                                    hipMemcpyDeviceToHost, st));
+        SD_HIP_CHECK(hipEventRecord(ev_done, st));
+        for (;;) {                                                // poll (see sd_spec_generate)
+            const hipError_t qe = hipEventQuery(ev_done);
+            if (qe == hipSuccess) break;
+            if (qe != hipErrorNotReady) { sd_set_error("sd_spec_batch_generate: %s", hipGetErrorString(qe)); rc = SD_ERR_HIP; break; }
+        }
+        if (rc != SD_OK) break;
+        if (iters < max_iters_log) {
+            float ms = 0.f;
+            if (verify_ms_out && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) verify_ms_out[iters] = ms;
+            if (verify_streams_out) verify_streams_out[iters] = n;
+            if (verify_ctx_out) verify_ctx_out[iters] = (float)(ctx / n + g);
+        }
+        ++iters;
+        bool failed = false;
+        for (int j = 0; j < n; ++j) {
+            sd_batch_stream &s = *act[j];
+            const sd_accept_result r = *s.res_host;
+            if (r.flags & (2 | 8)) { failed = true; break; }
+            const int L = Ls[j], l = r.n_accepted, nn = r.n;
+            if (s.acc_len_out) s.acc_len_out[s.calls] = l;
+            for (int i = 0; i < g; ++i) {
+                if (s.p_at_out) s.p_at_out[(size_t)s.calls * g + i] = r.p_at[i];
+                if (s.q_at_out) s.q_at_out[(size_t)s.calls * g + i] = r.q_at[i];
+            }
+            ++s.calls;
+            for (int i = 0; i < l; ++i) s.host_seq[s.len++] = r.drafted[i];
+            s.host_seq[s.len++] = r.next_token;
+            s.draft_len = std::min(L + g - 1, nn + 1);
+            s.target_len = nn + 1;
+            int eos_total = 0;
+            for (int i = 0; i < s.len; ++i) eos_total += s.host_seq[i] == eos_token_id;
+            if (eos_total > s.ori_eos_cnt) s.done = 1;            // the caller cuts after the first new EOS
+        }
+        if (failed) { *err_out = 1; break; }
+    }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev_done);
+    *n_iters_out = iters;
+    return rc;
+}

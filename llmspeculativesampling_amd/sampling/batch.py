@@ -15,8 +15,8 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from .._lib import lib, check, SdAcceptItem, SdAcceptResult, SdNormRow
-from ..engine import as_specdec_model, batch_forward, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device
+from .._lib import lib, check, SdAcceptResult, SdBatchStream
+from ..engine import as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device
 from ..noise import DeviceNoise
 from .kvcache_model import KVCacheModel
 
@@ -85,122 +85,75 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
         st.seq_ptr, st.err_ptr = st.seq32.data_ptr(), st.err.data_ptr()
         streams.append(st)
 
-    d_sessions = lambda ss: [s.draft._session for s in ss]
-    t_sessions = lambda ss: [s.target._session for s in ss]
+    # the lock-step loop itself runs inside libspecdec (sd_spec_batch_generate): per iteration gamma batched draft steps,
+    # the verify passes, the batched accept + residual sample, one copy of the result blocks and one wait - the
+    # interpreter sees the finished token buffers and the per-iteration statistics
     norm_ws = torch.empty(lib.sd_norm_workspace_bytes(MAX_ROWS_PER_FORWARD), dtype=torch.uint8, device=dev)
     cu = _stream()
-    res_base = res_dev.data_ptr()
-    ld_bytes = streams[0].draft._probs.stride(0) * 4
-    max_verify = max(1, MAX_ROWS_PER_FORWARD // (gamma + 1))     # streams per target pass
+    arr = (SdBatchStream * B)()
+    keep = []                                                     # host arrays the native loop writes into
+    max_iters = max(1, int(max_len)) + 1
+    for s in streams:
+        cap = s.T + gamma + 2
+        hs = np.zeros(cap, dtype=np.int32)
+        hs[:len(s.host)] = s.host
+        acc = np.zeros(max_iters, dtype=np.int32)
+        pa = np.zeros(max_iters * gamma, dtype=np.float32)
+        qa = np.ones(max_iters * gamma, dtype=np.float32)
+        keep.append((hs, acc, pa, qa))
+        it = arr[s.idx]
+        it.draft, it.target = s.draft._session.handle, s.target._session.handle
+        it.seq, it.q_hist, it.p_hist, it.err_words = s.seq_ptr, s.q_ptr, s.p_ptr, s.err_ptr
+        it.res_dev = res_dev.data_ptr() + s.idx * res_sz
+        it.res_host = res_host.data_ptr() + s.idx * res_sz
+        it.host_seq = hs.ctypes.data
+        it.len, it.T, it.ori_eos_cnt = len(s.host), s.T, s.ori_eos
+        it.draft_len, it.target_len = s.draft_len, s.target_len
+        it.seed, it.draw = s.noise.seed, s.noise.draw
+        it.acc_len_out, it.p_at_out, it.q_at_out = acc.ctypes.data, pa.ctypes.data, qa.ctypes.data
+    n_log = max_iters * 2
+    v_ms = np.zeros(n_log, dtype=np.float32)
+    v_n = np.zeros(n_log, dtype=np.int32)
+    v_ctx = np.zeros(n_log, dtype=np.float32)
+    c_iters, c_err = C.c_int(0), C.c_int(0)
+    d0, t0 = streams[0].draft._session, streams[0].target._session
+    check(lib.sd_spec_batch_generate(arr, B, gamma, float(temperature), int(top_k or 0), float(top_p or 0.0), V,
+                                     streams[0].draft._probs.stride(0), int(eos_token_id), int(random_seed or 0),
+                                     r_const.data_ptr() if r_const is not None else None, draft_m.norm_mode,
+                                     target_m.norm_mode, d0.logits.data_ptr(), d0.logits.stride(0), t0.logits.data_ptr(),
+                                     t0.logits.stride(0), norm_ws.data_ptr(), MAX_ROWS_PER_FORWARD,
+                                     v_ms.ctypes.data, v_n.ctypes.data, v_ctx.ctypes.data, n_log, C.byref(c_iters),
+                                     C.byref(c_err), cu), "sd_spec_batch_generate")
+    if c_err.value:
+        raise RuntimeError("s")
+    if _timing is not None:
+        class _Ms:                                                # (bench.py reads e0.elapsed_time(e1))
+            def __init__(self, ms):
+                self.ms = ms
 
-    while True:
-        act = [s for s in streams if not s.done and len(s.host) < s.T]
-        for s in streams:
-            if not s.done and len(s.host) >= s.T:
-                s.done = True
-        if not act:
-            break
-        n = len(act)
-        Ls = [len(s.host) for s in act]
-        base_draw = [s.noise.next_draws(gamma) for s in act]
-        # ---- draft: gamma steps over all active streams
-        for i in range(gamma):
-            n_new = [L + i - s.draft_len for s, L in zip(act, Ls)]
-            for s in act:
-                s.draft._session.cache_len = s.draft_len
-            logits = batch_forward(d_sessions(act), [s.seq32 for s in act], n_new, [1] * n)
-            rows = (SdNormRow * n)()
-            for j, (s, L) in enumerate(zip(act, Ls)):
-                # raw pointer arithmetic (one tensor view per row costs more host time than the kernels it feeds)
-                rows[j].probs_out = s.q_ptr + (L + i - 1) * ld_bytes
-                rows[j].err = s.err_ptr + 4 * i
-                rows[j].exp_noise = None
-                rows[j].philox_seed = s.noise.seed
-                rows[j].draw_index = base_draw[j] + i
-                rows[j].tok_out = s.seq_ptr + 4 * (L + i)
-                rows[j].sample_err = s.err_ptr + 4 * (gamma + i)
-                s.draft_len = L + i
-            check(lib.sd_norm_batch(logits.data_ptr(), n, V, logits.stride(0), float(temperature), int(top_k or 0),
-                                    float(top_p or 0.0), draft_m.norm_mode, rows, 1, norm_ws.data_ptr(), cu), "sd_norm_batch")
-        # ---- verify: the uncached rows of every stream, max_verify streams per pass over the target weights
-        if _timing is not None:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        for a in range(0, n, max_verify):
-            grp = act[a:a + max_verify]
-            gL = Ls[a:a + max_verify]
-            n_new = [L + gamma - s.target_len for s, L in zip(grp, gL)]
-            for s in grp:
-                s.target._session.cache_len = s.target_len
-            logits = batch_forward(t_sessions(grp), [s.seq32 for s in grp], n_new, n_new)
-            rows = (SdNormRow * sum(n_new))()
-            k = 0
-            for s, L, nn in zip(grp, gL, n_new):
-                for r in range(nn):
-                    pos = L + gamma - nn + r
-                    rows[k].probs_out = s.p_ptr + pos * ld_bytes
-                    rows[k].err = s.err_ptr + 4 * (2 * gamma + min(r, gamma))
-                    k += 1
-            check(lib.sd_norm_batch(logits.data_ptr(), k, V, logits.stride(0), float(temperature), int(top_k or 0),
-                                    float(top_p or 0.0), target_m.norm_mode, rows, 0, norm_ws.data_ptr(), cu), "sd_norm_batch")
-        if _timing is not None:
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
-            _timing.setdefault("verify", []).append((ev0, ev1, n, sum(Ls) / n + gamma))
-        # ---- accept scan + residual / bonus sample, all streams in two launches
-        items = (SdAcceptItem * n)()
-        for j, (s, L) in enumerate(zip(act, Ls)):
-            s.noise.next_draws(1)                                  # the discarded target sample
-            seed_before = s.noise.seed
-            if random_seed:
-                s.noise.reseed(random_seed)
-                d_scan = 0
-            else:
-                d_scan = s.noise.next_draws(gamma)
-            it = items[j]
-            it.p_hist = s.p_ptr
-            it.q_hist = s.q_ptr
-            it.seq = s.seq_ptr
-            it.L = L
-            it.r = r_const.data_ptr() if r_const is not None else None
-            it.exp_noise = None
-            it.philox_seed = s.noise.seed
-            it.draw_scan = d_scan
-            it.draw_resample = s.noise.next_draws(1)
-            it.res = res_base + s.idx * res_sz
-            it.err_flags = s.err_ptr
-            it.n_err = n_err
-        res_mode = target_m.norm_mode if target_m.norm_mode == draft_m.norm_mode else 0
-        check(lib.sd_accept_batch(items, n, act[0].draft._probs.stride(0), V, gamma, res_mode, cu), "sd_accept_batch")
-        res_host.copy_(res_dev, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        raw = res_host.numpy()
-        for s, L in zip(act, Ls):
-            res = SdAcceptResult.from_buffer_copy(raw[s.idx].tobytes())
-            if res.flags & 2:
-                raise RuntimeError("s")
-            if res.flags & 8:
-                raise RuntimeError("s")
-            l, nn, t = res.n_accepted, res.n, res.next_token
-            for i in range(gamma):
-                s.acc_rate.append(min(1.0, float(res.p_at[i]) / float(res.q_at[i])))
-            s.acc_len.append(l)
-            s.calls += 1
-            s.host = s.host + [int(res.drafted[i]) for i in range(l)] + [t]
-            s.draft_len = min(L + gamma - 1, nn + 1)
-            s.target_len = nn + 1
-            s.out = s.host
-            eos_total = sum(1 for x in s.host if x == eos_token_id)
-            if eos_total > s.ori_eos:
-                seen, cut = 0, len(s.host)
-                for idx, x in enumerate(s.host):
-                    if x == eos_token_id:
-                        seen += 1
-                        if seen == s.ori_eos + 1:
-                            cut = idx + 1
-                            break
-                s.out = s.host[:cut]
-                s.done = True
+            def elapsed_time(self, _other):
+                return self.ms
+        for i in range(min(c_iters.value, n_log)):
+            _timing.setdefault("verify", []).append((_Ms(float(v_ms[i])), None, int(v_n[i]), float(v_ctx[i])))
+    for s, (hs, acc, pa, qa) in zip(streams, keep):
+        it = arr[s.idx]
+        s.host = hs[:it.len].tolist()
+        s.calls = it.calls
+        s.acc_len = acc[:it.calls].tolist()
+        s.acc_rate = np.minimum(1.0, pa[:it.calls * gamma].astype(np.float64) / qa[:it.calls * gamma].astype(np.float64)).tolist()
+        s.draft_len, s.target_len = it.draft_len, it.target_len
+        s.noise.seed, s.noise.draw = it.seed, it.draw
+        s.draft._session.cache_len, s.target._session.cache_len = s.draft_len, s.target_len
+        s.out = s.host
+        if sum(1 for x in s.host if x == eos_token_id) > s.ori_eos:
+            seen, cut = 0, len(s.host)
+            for idx, x in enumerate(s.host):
+                if x == eos_token_id:
+                    seen += 1
+                    if seen == s.ori_eos + 1:
+                        cut = idx + 1
+                        break
+            s.out = s.host[:cut]
 
     outs = [torch.tensor([s.out], dtype=torch.int64, device=prefixes[i].device) for i, s in enumerate(streams)]
     if details:

@@ -34,6 +34,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.SdAcceptResult) == 16 + 64 + 64 + 64
     assert C.sizeof(_lib.SdMultiResult) == 208 + 16 + 2 * 1024 and C.sizeof(_lib.SdMultiItem) == 24
     assert C.sizeof(_lib.SdModelConfig) == 15 * 4
+    assert C.sizeof(_lib.SdBatchStream) == 9 * 8 + 5 * 4 + 4 + 2 * 8 + 2 * 4 + 3 * 8      # (4 bytes of padding before `seed`)
     assert C.sizeof(_lib.SdModelWeights) == 21 * 8
 
 
