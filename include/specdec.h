@@ -153,6 +153,21 @@ int sd_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_
                 int gamma, const float *exp_noise, uint64_t philox_seed, uint64_t draw_index,
                 sd_accept_result *res, int32_t *seq_len, int dtype_mode, void *stream);
 
+/* sd_accept_scan + sd_resample in ONE launch whose sample works on candidate lists instead of two passes over V.
+ * sd_norm_probs_lists is sd_norm_probs that also leaves, per row, the row's non-zero entries (token ids + probabilities;
+ * sd_cand_list_bytes(rows) device bytes; a row gets a list when 1 <= top_k <= 64 put it through the candidate path and it
+ * holds <= 128 entries, else it is marked list-less).  sd_accept_resample takes the lists of the gamma + 1 TARGET rows of
+ * the iteration (positions L-1 .. L+gamma-1, in order) or NULL; results are bit-identical to the two-kernel form, which
+ * it falls back to for a list-less row.  Philox only (seed, draw_scan + i for the uniforms unless r is given; draw_resample). */
+size_t sd_cand_list_bytes(int rows);
+int sd_norm_probs_lists(const float *logits, int rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                        int bf16_round_logits, float *probs_out, long ld_out, int *err_flag, void *workspace,
+                        void *cand_lists, void *stream);
+int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
+                       const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
+                       sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode, const void *target_lists,
+                       void *stream);
+
 /* sd_accept_scan + sd_resample for up to 16 independent streams in two launches (stream-batched decode).
  * Per item: its probability arenas, token buffer, prefix length L, the gamma uniforms r (or NULL: Philox
  * (philox_seed, draw_scan + i)), the resample noise row (or NULL: Philox (philox_seed, draw_resample)), the

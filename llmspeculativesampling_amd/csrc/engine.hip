@@ -1586,10 +1586,6 @@ int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, fl
                             uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
                             void *stream, void *cand_lists);
 size_t sd_norm_candrow_bytes(int rows);
-int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
-                       const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
-                       sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode, const void *target_lists,
-                       hipStream_t st);
 
 // feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows, all of them from the
 // final call (a chunk never ends inside the logits rows), so that call's output slab can be handed to the norm as is

@@ -1175,7 +1175,17 @@ int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, fl
                        tok_out != nullptr, nullptr, seed, draw, tok_out, samp_err, workspace, stream, nullptr, 0, tile_max,
                        static_cast<CandList *>(cand_lists));
 }
-size_t sd_cand_list_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandList); }
+extern "C" size_t sd_cand_list_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * sizeof(CandList); }
+extern "C" int sd_norm_probs_lists(const float *logits, int rows, int V, long ld_in, float temperature, int top_k,
+                                   float top_p, int bf16_round_logits, float *probs_out, long ld_out, int *err_flag,
+                                   void *workspace, void *cand_lists, void *stream) {
+    SD_REQUIRE(logits && probs_out && cand_lists && rows >= 0 && V > 0, "sd_norm_probs_lists: bad arguments");
+    SD_REQUIRE(temperature != 0.0f, "sd_norm_probs_lists: temperature must be non-zero");
+    if (rows == 0) return SD_OK;
+    return launch_norm(logits, rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, probs_out, ld_out, err_flag,
+                       false, nullptr, 0, 0, nullptr, nullptr, workspace, stream, nullptr, 0, nullptr,
+                       static_cast<CandList *>(cand_lists));
+}
 
 // top_k_top_p_filter on its own (utils.py:152-179): out = logit where kept, -inf where dropped (out != logits).
 extern "C" int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p,
@@ -1403,11 +1413,13 @@ __global__ __launch_bounds__(NT) void accept_resample_kernel(const float *__rest
     }
 }
 
-// internal (sd_spec_iteration): accept scan + resample with the iteration's error words, target-row candidate lists or NULL
-int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
-                       const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
-                       sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode, const void *target_lists,
-                       hipStream_t st) {
+extern "C" int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
+                                  const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
+                                  sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode,
+                                  const void *target_lists, void *stream) {
+    SD_REQUIRE(p_hist && q_hist && seq && res && gamma >= 1 && gamma <= 16 && L >= 1 && V > 0 && (n_err == 0 || err_flags),
+               "sd_accept_resample: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(accept_resample_kernel, dim3(1), dim3(NT), 0, st, p_hist, q_hist, ld, V, seq, L, gamma, r, philox_seed,
                        draw_scan, draw_resample, res, err_flags, n_err, mode_dt(dtype_mode),
                        static_cast<const CandList *>(target_lists));

@@ -231,6 +231,72 @@ def test_accept_resample_kernels_golden(hip, case):
     assert nz.exhausted()
 
 
+@pytest.mark.parametrize("mode", ["philox", "always_reject_equal_rows", "all_accept"])
+def test_fused_accept_resample_on_candidate_lists_equals_the_two_dense_kernels(hip, mode):
+    """sd_accept_resample (one launch, the sample working on the target rows' candidate lists from sd_norm_probs_lists)
+    against sd_accept_scan + sd_resample (two launches, two passes over V) on the same rows, drafted tokens and Philox
+    draws: the whole result block and the appended token must be identical.  The strong tokens' ids agree modulo 1024, so
+    several candidates share one per-thread partial of the dense normaliser sum (the fused kernel has to add them in
+    index order); `always_reject_equal_rows` (p == q, r = 1.5) forces the zero-residual fallback sample(max_fn(p_n));
+    `all_accept` the bonus sample."""
+    lib = hip.lib
+    V, gamma, L = 32000, 4, 7
+    S = L + gamma + 1
+    rng = np.random.default_rng(77)
+    res_sz = C.sizeof(hip.L.SdAcceptResult)
+    for trial in range(12):
+        z = (rng.standard_normal((S, V)) * 2.0).astype(np.float32)
+        base = int(rng.integers(0, 1024))
+        strong = [base + 1024 * int(k) for k in rng.choice(31, size=7, replace=False)]
+        z[:, strong] += 8.0 + rng.standard_normal((S, len(strong))).astype(np.float32)
+        sigma = 0.0 if mode != "philox" else [0.3, 1.0, 3.0][trial % 3]
+        zp = z + np.float32(sigma) * (rng.standard_normal((S, V)) * 2.0).astype(np.float32)
+        q_hist = hip.S.norm_logits(torch.from_numpy(z).cuda(), 1.0, 20, 0.9).contiguous()
+        p_hist = torch.zeros((S, V), dtype=torch.float32, device="cuda")
+        rows = gamma + 1
+        ws = torch.empty(lib.sd_norm_workspace_bytes(rows), dtype=torch.uint8, device="cuda")
+        lists = torch.empty(lib.sd_cand_list_bytes(rows), dtype=torch.uint8, device="cuda")
+        zt = torch.from_numpy(zp).cuda()
+        err = torch.zeros(rows, dtype=torch.int32, device="cuda")
+        hip.L.check(lib.sd_norm_probs_lists(zt[L - 1].data_ptr(), rows, V, V, 1.0, 20, 0.9, 0, p_hist[L - 1].data_ptr(), V,
+                                            err.data_ptr(), ws.data_ptr(), lists.data_ptr(), _st()))
+        assert torch.equal(p_hist[L - 1:L + gamma], hip.S.norm_logits(zt[L - 1:L + gamma], 1.0, 20, 0.9))
+        n_list = np.frombuffer(lists.cpu().numpy().tobytes(), dtype=np.int32).reshape(rows, -1)[:, 0]
+        assert (n_list > 0).all() and (n_list <= 20).all()         # every row got its list
+        seq0 = torch.zeros(S + 8, dtype=torch.int32, device="cuda")
+        seq0[:L] = torch.from_numpy(rng.integers(3, V, size=L).astype(np.int32)).cuda()
+        serr = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for i in range(gamma):                                     # the drafted tokens: samples of the q rows
+            hip.L.check(lib.sd_sample(q_hist[L + i - 1].data_ptr(), V, None, 11 + trial, i, seq0[L + i].data_ptr(),
+                                      serr.data_ptr(), 0, _st()))
+        r = None
+        if mode == "always_reject_equal_rows":
+            r = torch.full((gamma,), 1.5, dtype=torch.float32, device="cuda")
+        seed, d_scan, d_res = 1000 + trial, 5, 9
+        out = {}
+        for which in ("dense", "fused"):
+            seq = seq0.clone()
+            res = torch.zeros(res_sz, dtype=torch.uint8, device="cuda")
+            if which == "dense":
+                hip.L.check(lib.sd_accept_scan(p_hist.data_ptr(), q_hist.data_ptr(), V, seq.data_ptr(), L, gamma,
+                                               r.data_ptr() if r is not None else None, seed, d_scan, res.data_ptr(), _st()))
+                hip.L.check(lib.sd_resample(p_hist.data_ptr(), q_hist.data_ptr(), V, V, seq.data_ptr(), L, gamma, None, seed,
+                                            d_res, res.data_ptr(), None, 0, _st()))
+            else:
+                hip.L.check(lib.sd_accept_resample(p_hist.data_ptr(), q_hist.data_ptr(), V, V, seq.data_ptr(), L, gamma,
+                                                   r.data_ptr() if r is not None else None, seed, d_scan, d_res,
+                                                   res.data_ptr(), None, 0, 0, lists.data_ptr(), _st()))
+            out[which] = (res.cpu().numpy().tobytes(), seq.cpu().numpy().copy())
+        a = hip.L.SdAcceptResult.from_buffer_copy(out["dense"][0])
+        assert out["fused"][0] == out["dense"][0], (trial, a.n_accepted, a.next_token)
+        np.testing.assert_array_equal(out["fused"][1], out["dense"][1])
+        assert a.next_token >= 0
+        if mode == "always_reject_equal_rows":
+            assert a.n_accepted == 0 and (a.flags & 1)             # the residual was empty: fallback taken
+        if mode == "all_accept":
+            assert a.n_accepted == gamma
+
+
 def test_resample_fallback_when_residual_is_zero(hip):
     """p == q at the rejected position: max_fn(p-q) is all zero, the reference's sample raises and it
     falls back to sample(max_fn(p)) (speculative_sampling.py:2007-2010)."""
