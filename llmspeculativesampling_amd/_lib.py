@@ -141,6 +141,10 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m llmspeculativesampling_amd._build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+    # torch first: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), and libspecdec.so must bind to THAT
+    # instance - loaded before torch it would pull in /opt/rocm's copy, the process would hold two runtimes, and the first
+    # kernel launch on torch's device pointers would fail with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError here = header and library disagree

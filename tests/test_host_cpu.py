@@ -339,3 +339,18 @@ def test_tree_helpers_match_reference_fixtures():
                                               [torch.tensor([5, 6, 7]), torch.tensor([8, 9, 10])], 4, 99)
     assert seq.tolist() == [[5, 7, 8], [6, 9, 10]] and pos[:2].tolist() == [[0, -1], [1, -1]]
     assert pids.tolist() == [[4, 4, 5], [4, 5, 5]]
+
+
+def test_library_binds_to_the_hip_runtime_torch_loaded():
+    """libspecdec.so has to share ONE HIP runtime with torch (which ships its own libamdhip64): loaded before torch it
+    pulls in /opt/rocm's copy, and the first launch on a torch device pointer then fails with "no ROCm-capable device"
+    (seen with __graft_entry__.build() followed by smoke() in one process).  _lib therefore imports torch first."""
+    import subprocess
+    import sys
+    code = ("import sys; import llmspeculativesampling_amd._lib as L; assert 'torch' in sys.modules; "
+            "maps = open('/proc/self/maps').read(); "
+            "hips = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}); "
+            "assert len(hips) == 1, hips; print(hips[0])")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "torch" in out.stdout                                   # the one runtime in the process is torch's copy
