@@ -354,3 +354,24 @@ def test_library_binds_to_the_hip_runtime_torch_loaded():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "torch" in out.stdout                                   # the one runtime in the process is torch's copy
+
+
+def test_new_entry_points_reject_null_arguments_without_a_gpu():
+    """Argument validation of the round-2 entries happens before any HIP call: NULL handles / buffers come back as
+    SD_ERR_INVALID with a message (no GPU needed)."""
+    import ctypes as C
+    from llmspeculativesampling_amd import _lib
+    lib = _lib.lib
+    z = C.c_int(0)
+    assert lib.sd_spec_generate(None, None, None, 8, 2, 0, None, None, 0, None, None, None, None, 1, None, None, None, None,
+                                None, C.byref(z), C.byref(z), None) == _lib.SD_ERR_INVALID
+    assert b"sd_spec_generate" in lib.sd_last_error()
+    assert lib.sd_spec_batch_generate(None, 0, 4, 1.0, 20, 0.9, 32000, 32000, 2, 0, None, 0, 0, None, 0, None, 0, None, 64,
+                                      None, None, None, 0, C.byref(z), C.byref(z), None) == _lib.SD_ERR_INVALID
+    assert b"sd_spec_batch_generate" in lib.sd_last_error()
+    assert lib.sd_accept_resample(None, None, 32000, 32000, None, 4, 4, None, 1, 0, 0, None, None, 0, 0, None, None) \
+        == _lib.SD_ERR_INVALID
+    assert lib.sd_norm_probs_lists(None, 1, 32000, 32000, 1.0, 20, 0.9, 0, None, 32000, None, None, None, None) \
+        == _lib.SD_ERR_INVALID
+    assert lib.sd_session_chain_status(None, None) == _lib.SD_ERR_INVALID
+    assert lib.sd_cand_list_bytes(3) == 3 * (4 + 128 * 4 + 128 * 4) and lib.sd_cand_list_bytes(0) == 0
