@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timeline of one decode iteration from a rocprofv3 --kernel-trace CSV: for every launch of the last complete
-iteration (anchored on accept_scan_kernel) its start offset, duration and the idle gap before it, plus totals per phase.
+iteration (anchored on the accept kernel: accept_resample_kernel, or accept_scan_kernel) its start offset, duration and the idle gap before it, plus totals per phase.
 
     rocprofv3 --kernel-trace -d out -- python3 bench.py --steps 1 --warmup 1 --max-len 24 --cpu-baseline 0 --profile-classes 0
     python tools/trace_gaps.py out/**/*kernel_trace.csv
@@ -12,7 +12,7 @@ import sys
 def short(n):
     n = n.replace("void ", "")
     for k in ("gemm_bf16_stream", "attn_kernel", "residual_norm_kernel", "norm_probs_kernel", "norm_cand_kernel",
-              "embed_kernel", "norm_kernel", "logits_kernel", "accept_scan", "resample_kernel", "qkv_epilogue", "act_kernel"):
+              "embed_norm_kernel", "embed_kernel", "norm_kernel", "logits_kernel", "accept_resample_kernel", "accept_scan", "resample_kernel", "gemm_small", "qkv_epilogue", "act_kernel"):
         if k in n:
             return k
     return n[:40]
@@ -21,7 +21,7 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-scans = [i for i, n in enumerate(names) if "accept_scan" in n]
+scans = [i for i, n in enumerate(names) if "accept_scan" in n or "accept_resample" in n]
 if len(scans) < 3:
     sys.exit("need at least three iterations in the trace")
 a, b = scans[-3], scans[-2]                   # kernels after scan a's resample up to scan b + resample = one iteration
