@@ -1,0 +1,250 @@
+"""Round-3 parity tests at production shapes (`pytest -m gpu`), VERDICT r2 "next" item 1.
+
+No bar in this file is set from a measurement of the HIP path:
+
+* bf16 forwards are held to the rule "HIP's error against an fp32 forward of the same (bf16-valued) weights is at most
+  1.5x the error of the reference's own bf16 arithmetic (the oracle run in bf16) against that fp32 forward" - at depths
+  2, 8, 16 and at the full 40 layers of Llama-2-13b and OPT-13b.  Two correct bf16 evaluations that round in a different
+  order sit at the same distance from the fp32 truth; a kernel that drops a rounding step, a k-step or a mask entry does
+  not.  The factor 1.5 is the round-2 test's (depth 2); it is kept, not re-fitted.
+* integer-valued operands make every dot product exact in fp32 in ANY summation order, so the MFMA GEMM kernels (every
+  row-count class of the streaming kernel, the LDS-tiled kernel, the balanced many-row kernel, all split-K folds) must
+  reproduce an integer matmul bit for bit at the production shapes.
+* a toy pair whose GEMMs are exact by construction (sparse few-bit weights) runs the whole native loop through the MFMA
+  kernels, the MFMA attention and the fused epilogues token for token against the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from philox_replay import PhiloxOracleNoise
+from llmspeculativesampling_amd.config import ModelConfig, load_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import types
+    import llmspeculativesampling_amd.sampling as S
+    from llmspeculativesampling_amd import _lib, engine, noise
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    return types.SimpleNamespace(S=S, lib=_lib.lib, L=_lib, engine=engine, noise=noise)
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _host_sd(m):
+    return {n: m._synth_get(n).cpu() for n in m._synth_names}
+
+
+def _truth_errors(hip, cfg, seed, label):
+    """HIP bf16 forward and oracle bf16 forward against the oracle fp32 forward of the same bf16-valued weights:
+    a 23-row prefill, then a gamma+1 = 5-row verify whose logits are compared.  Returns the oracle's bf16 logits too."""
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=seed, dtype=torch.bfloat16, max_pos=64)
+    sd16 = _host_sd(m)
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 28)))
+    ses = m.new_session(64)
+    ses.forward(ids[0, :23].to(torch.int32).cuda(), 0)
+    got = ses.forward(ids[0, 23:28].to(torch.int32).cuda(), 5).cpu()
+    del ses, m
+    torch.cuda.empty_cache()
+    o16 = oracle.RefCausalLM(cfg, sd16)
+    r = o16(ids[:, :23])
+    ref16 = o16(ids[:, 23:28], past_key_values=r.past_key_values).logits.float()[0]
+    del o16, r
+    sd32 = {k: v.float() for k, v in sd16.items()}
+    del sd16
+    o32 = oracle.RefCausalLM(cfg, sd32)
+    r = o32(ids[:, :23])
+    truth = o32(ids[:, 23:28], past_key_values=r.past_key_values).logits.float()[0]
+    del o32, r, sd32
+    e_hip, e_ref = float((got - truth).abs().max()), float((ref16 - truth).abs().max())
+    rms_hip = float((got - truth).pow(2).mean().sqrt())
+    rms_ref = float((ref16 - truth).pow(2).mean().sqrt())
+    print(f"{label}: |logit| max {float(truth.abs().max()):.2f}; max err hip {e_hip:.4f} ref-bf16 {e_ref:.4f}; "
+          f"rms hip {rms_hip:.5f} ref-bf16 {rms_ref:.5f}; hip vs ref-bf16 max {float((got - ref16).abs().max()):.4f}")
+    return got, ref16, truth, (e_hip, e_ref, rms_hip, rms_ref)
+
+
+def _assert_within_reference_error(errs, label):
+    e_hip, e_ref, rms_hip, rms_ref = errs
+    assert rms_hip <= 1.5 * rms_ref + 1e-3, (label, rms_hip, rms_ref)
+    assert e_hip <= 1.5 * e_ref + 0.02, (label, e_hip, e_ref)
+
+
+@pytest.mark.parametrize("depth", [2, 8, 16, 40])
+def test_llama13b_shape_bf16_error_vs_fp32_truth_at_depth(hip, depth):
+    """Llama-2-13b's layer shape (hidden 5120, 40 heads x 128, inter 13824, vocab 32000) at 2 / 8 / 16 / all 40 layers,
+    bf16: the verify rows' logits after a 23-row prefill.  At every depth the HIP forward must be no further from the
+    fp32 truth than 1.5x the reference's own bf16 arithmetic is (reference modeling_llama.py:405-457, 75-89; oracle
+    models_ref.py).  This replaces reading the 40-layer "4 % of the logit scale" figure as a measured bar: that figure
+    is what two bf16 evaluations 40 layers deep differ by, and this test shows the HIP one is not the outlier."""
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=depth,
+                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=256, rms_norm_eps=1e-5)
+    _, _, _, errs = _truth_errors(hip, cfg, seed=9, label=f"llama-13b shape, {depth} layers")
+    _assert_within_reference_error(errs, f"depth {depth}")
+
+
+def test_opt13b_config3_first_verify_vs_oracle_full_size(hip):
+    """BASELINE configs[2] at its real shapes: opt-125m -> opt-13b, bf16 (ffn 20480, V 50272, LayerNorm + biases, learned
+    positions + 2, tied head, logits kept in bf16: reference modeling_opt.py:160-278, 864-997).  A 23-token prompt and a
+    5-row verify on the same synthetic weights: (i) target logits vs the fp32 truth under the 1.5x rule, (ii) the bf16
+    probability rows norm_logits makes of them (T = 1, k = 20, p = 0.9; reference utils.py:182-210) against
+    oracle.norm_logits of the oracle's bf16 logits: wherever the two bf16 logit rows agree on the top-20 set, the
+    supports must be identical up to ties at the cut, and the draft's prefill + step likewise."""
+    tcfg, dcfg = load_config("opt-13b"), load_config("opt-125m")
+    got, ref16, truth, errs = _truth_errors(hip, tcfg, seed=2, label="opt-13b")
+    _assert_within_reference_error(errs, "opt-13b")
+    # OPT's logits are bf16 values (modeling_opt.py:974): the HIP rows must already be rounded
+    assert torch.equal(got, got.to(torch.bfloat16).float())
+    p_hip = hip.S.norm_logits(got.cuda().to(torch.bfloat16), 1.0, 20, 0.9).float().cpu()
+    for i in range(5):
+        p_ref = oracle.norm_logits(ref16[i:i + 1].to(torch.bfloat16), 1.0, 20, 0.9)[0].float()
+        p_self = oracle.norm_logits(got[i:i + 1].to(torch.bfloat16), 1.0, 20, 0.9)[0].float()
+        # the HIP sampler on HIP's own logits is the oracle's sampler on those logits (ties at the top-p cut aside: G8)
+        same = (p_hip[i] > 0) == (p_self > 0)
+        assert int((~same).sum()) <= 2, (i, int((~same).sum()))
+        on = same & (p_self > 0)
+        assert float((p_hip[i][on] - p_self[on]).abs().max()) <= 2 ** -7 * float(p_self.max())
+        # in probability space the same rule as for the logits: distance to the rows of the (bf16-rounded) fp32 truth
+        p_true = oracle.norm_logits(truth[i:i + 1].to(torch.bfloat16), 1.0, 20, 0.9)[0].float()
+        tv_hip = 0.5 * float((p_hip[i] - p_true).abs().sum())
+        tv_ref = 0.5 * float((p_ref - p_true).abs().sum())
+        print(f"opt-13b row {i}: TV to the truth's row: hip {tv_hip:.3f}, ref-bf16 {tv_ref:.3f}")
+        assert tv_hip <= 1.5 * tv_ref + 0.05, (i, tv_hip, tv_ref)
+    _, _, _, derrs = _truth_errors(hip, dcfg, seed=1, label="opt-125m")
+    _assert_within_reference_error(derrs, "opt-125m")
+
+
+# --------------------------------------------------------------------------- integer-exact MFMA GEMMs
+GEMM_SHAPES = {                                                   # [N][K] of the per-layer GEMMs the bench configs run
+    "13b_qkv": (15360, 5120), "13b_o": (5120, 5120), "13b_gate_up": (27648, 5120), "13b_down": (5120, 13824),
+    "13b_lm_head": (32000, 5120), "68m_qkv": (2304, 768), "68m_lm_head": (32000, 768), "opt13b_fc1": (20480, 5120),
+    "70b_down": (8192, 28672),
+}
+
+
+@pytest.mark.parametrize("shape", list(GEMM_SHAPES))
+def test_mfma_gemm_is_integer_exact_at_production_shapes(hip, shape):
+    """W in {-2..2}, X in {-4..4} (exact in bf16): every product and every partial sum is an integer below 2^24, so the
+    fp32 result is the same in any summation order and the kernels - MFMA accumulation, in-workgroup fold, split-K slabs
+    and their reduction - must equal an integer matmul bit for bit.  Row counts cover every dispatch class of
+    sd_gemm_bf16: 1, 5 (decode / verify), 16, 17, 40, 60, 64 (stream-batched verify), 128 and 256 (prefill chunks)."""
+    N, K = GEMM_SHAPES[shape]
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    W = torch.randint(-2, 3, (N, K), device="cuda", generator=g).to(torch.bfloat16)
+    Wp = torch.empty_like(W)
+    assert hip.lib.sd_pack_weight_bf16(W.data_ptr(), Wp.data_ptr(), N, K, _st()) == 0
+    Wf = W.double()
+    part = torch.empty(64 * 64 * N if N <= 8192 else 20 * 256 * N, dtype=torch.float32, device="cuda")
+    for M in (1, 5, 16, 17, 40, 60, 64, 128, 256):
+        X = torch.randint(-4, 5, (M, K), device="cuda", generator=g).to(torch.bfloat16)
+        Xt = torch.zeros((M + 15) // 16 * 16 * K, device="cuda", dtype=torch.bfloat16)
+        assert hip.lib.sd_pack_activation_bf16(X.data_ptr(), Xt.data_ptr(), M, K, _st()) == 0
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        S = C.c_int(0)
+        rc = hip.lib.sd_gemm_bf16(Wp.data_ptr(), Xt.data_ptr(), 1, M, N, K, part.data_ptr(), part.numel(), out.data_ptr(),
+                                  C.byref(S), _st())
+        assert rc == 0, hip.L.last_error() if hasattr(hip.L, "last_error") else rc
+        want = (X.double() @ Wf.t()).float()
+        assert torch.equal(out, want), (shape, M, S.value, float((out - want).abs().max()))
+        if M <= 64:                                               # plain-row operand of the public entry
+            out.fill_(float("nan"))
+            assert hip.lib.sd_gemm_bf16(Wp.data_ptr(), X.data_ptr(), 0, M, N, K, part.data_ptr(), part.numel(),
+                                        out.data_ptr(), None, _st()) == 0
+            assert torch.equal(out, want), (shape, M, "row-major")
+
+
+# --------------------------------------------------------------------------- token-exact run through the MFMA path
+def _fewbit_sparse_sd(cfg: ModelConfig, seed: int, nnz: int = 4):
+    """bf16 state dict whose GEMMs are exact in any summation order: every weight row has `nnz` non-zero entries, each
+    +-2^j (one significant bit), so a dot product is a sum of `nnz` terms that are bf16 activations shifted by powers of
+    two - exact in fp32 unless the terms are more than 15 binades apart.  Norm weights are exactly 1."""
+    from llmspeculativesampling_amd.synth import param_shapes
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shape, kind in param_shapes(cfg):
+        if kind == "norm_w":
+            a = np.ones(shape, dtype=np.float32)
+        elif kind == "emb":
+            a = rng.choice(np.array([-1.5, -1.0, -0.5, 0.5, 1.0, 1.5], dtype=np.float32), size=shape)
+        else:
+            rows, cols = shape
+            a = np.zeros(shape, dtype=np.float32)
+            idx = np.stack([rng.choice(cols, size=nnz, replace=False) for _ in range(rows)])
+            mag = 2.0 ** rng.integers(-2, 1, size=(rows, nnz)) * (2.0 if kind == "head" else 1.0) / np.sqrt(nnz)
+            mag = 2.0 ** np.round(np.log2(mag))
+            a[np.arange(rows)[:, None], idx] = (mag * rng.choice([-1.0, 1.0], size=(rows, nnz))).astype(np.float32)
+        sd[name] = torch.from_numpy(a).to(torch.bfloat16)
+    return sd
+
+
+def _perturb_fewbit(sd, seed, frac):
+    """target = draft with a fraction of the matrix rows redrawn (keeps the few-bit sparse structure)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, t in sd.items():
+        t = t.clone()
+        if t.dim() == 2 and "embed" not in name:
+            rows = np.nonzero(rng.random(t.shape[0]) < frac)[0]
+            for r in rows:
+                t[r] = t[r][torch.from_numpy(rng.permutation(t.shape[1]))]
+        out[name] = t
+    return out
+
+
+TOKEN_EXACT_CASES = [("g4_a", 0.08, 4, 5), ("g4_b", 0.0, 4, 6), ("g2", 0.15, 2, 7), ("g4_c", 0.3, 4, 8)]
+
+
+@pytest.mark.parametrize("name,frac,gamma,seed", TOKEN_EXACT_CASES, ids=[c[0] for c in TOKEN_EXACT_CASES])
+def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac, gamma, seed):
+    """The bf16 engine (gemm_bf16_stream with the fused QKV / SiLU / head epilogues, the MFMA attention kernel, the
+    native loop sd_spec_generate with device Philox) against the oracle's bf16 CPU run fed the same Philox variates,
+    token for token, accept length for accept length.  Every fp32 test of this kind goes through gemm_f32_simple; here the
+    pair is built so that bf16 rounding ORDER cannot separate the two implementations in the GEMMs (see
+    _fewbit_sparse_sd: dot products of 4 power-of-two-scaled terms are exact).  What is left order-dependent is fp32
+    statistics of norms / softmax (a bf16 result flips only if an fp32 last-bit difference straddles a bf16 rounding
+    boundary, ~1e-5 per element): the pair is small (hidden 64, one layer draft / two layer target, <= 16 new tokens,
+    ~1e5 rounded elements per trace in all), so the expected number of such events per trace is ~0.1 and a flipped
+    element moves a sampling decision only when that decision was within ~1 % anyway.  The run is deterministic."""
+    V = 512
+    dcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                       num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128, rms_norm_eps=1e-5)
+    tcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=128, rms_norm_eps=1e-5)
+    dsd = _fewbit_sparse_sd(dcfg, seed)
+    tsd = _fewbit_sparse_sd(tcfg, seed + 100)
+    # correlate the pair: the target shares the draft's embedding, first layer (its K / V rows are cut to the single KV
+    # head) and head, with a fraction of rows redrawn
+    shared = _perturb_fewbit(dsd, seed + 200, frac)
+    hd = tcfg.head_dim
+    for k, v in shared.items():
+        if k in tsd and tsd[k].shape == v.shape:
+            tsd[k] = v
+        elif k in tsd and k.endswith(("k_proj.weight", "v_proj.weight")):
+            tsd[k] = v[:hd]
+    prompt = torch.from_numpy(np.random.default_rng(seed).integers(3, V, size=(1, 9)))
+    kw = dict(gamma=gamma, top_k=20, top_p=0.9)
+    want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd), -1, None, 16,
+                                           details=True, noise=PhiloxOracleNoise(hip.lib, 4242 + seed, gamma, _st), **kw)
+    dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.bfloat16)
+    tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.bfloat16)
+    assert dm.fused and tm.fused                                  # the fused-epilogue MFMA route, not the fp32 kernels
+    got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 16, details=True,
+                                         rng=hip.noise.DeviceNoise(4242 + seed), **kw)
+    print(name, "acc_len oracle", wd["acc_len"], "hip", gd["acc_len"])
+    np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+    assert gd["acc_len"] == wd["acc_len"]
+    assert gd["target_call_times"] == wd["target_call_times"]
+    assert 0 < sum(wd["acc_len"]) < gamma * len(wd["acc_len"])    # the scenario has partial accepts (oracle's own run)
+    # the Python-orchestrated loop (dense accept / resample kernels) agrees bit for bit too
+    got2, gd2 = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 16, details=True, verbose=True,
+                                           rng=hip.noise.DeviceNoise(4242 + seed), **kw)
+    assert torch.equal(got, got2) and gd["acc_len"] == gd2["acc_len"]
