@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SD_ABI_VERSION 2
+#define SD_ABI_VERSION 3
 
 typedef enum {
     SD_OK = 0,
@@ -76,9 +76,11 @@ size_t sd_norm_workspace_bytes(int rows);
 
 /* top_k_top_p_filter by itself (utils.py:152-179; the reference mutates its argument and returns it): out[i] = logit
  * where the token is kept, -inf where it is dropped; top_k == 0 and top_p == 0 leave the row untouched.  `out` must
- * not alias `logits` (the Python drop-in copies the result back into its argument). */
-int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p, float *out,
-                        long ld_out, void *stream);
+ * not alias `logits` (the Python drop-in copies the result back into its argument).  dtype_mode: 0, or SD_NORM_DT_BF16 /
+ * SD_NORM_DT_F16 when the caller's tensor is 16-bit - the reference then sorts, softmaxes and cumsums in that dtype
+ * (utils.py:170-172), so the kept set near the top-p cut is decided on 16-bit sums, exactly as sd_norm_probs decides it. */
+int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p, int dtype_mode,
+                        float *out, long ld_out, void *stream);
 
 /* One draft / autoregressive step's tail fused: norm_logits of ONE row followed by sample() on it
  * (kvcache_model.py:235-236 + :283), a single launch.  Writes the probability row (the accept scan and

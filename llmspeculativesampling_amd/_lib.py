@@ -85,7 +85,7 @@ SYMBOLS = [
     ("sd_version", _I, []),
     ("sd_last_error", C.c_char_p, []),
     ("sd_norm_probs", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP, _VP]),
-    ("sd_topk_topp_filter", _I, [_VP, _I, _I, _L, _I, _F, _VP, _L, _VP]),
+    ("sd_topk_topp_filter", _I, [_VP, _I, _I, _L, _I, _F, _I, _VP, _L, _VP]),
     ("sd_norm_workspace_bytes", C.c_size_t, [_I]),
     ("sd_norm_sample", _I, [_VP, _I, _F, _I, _F, _I, _VP, _VP, _VP, _U64, _U64, _VP, _VP, _VP, _VP]),
     ("sd_norm_batch", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, C.POINTER(SdNormRow), _I, _VP, _VP]),

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <vector>
 
 #include "model_kernels.h"
@@ -138,6 +139,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // per launch: a draft step is ~40 getenv() scans otherwise, on the host thread that has to keep the GPU fed.
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
+    int attn_split_keys = 384, attn_keys_per_split = 256;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -149,6 +151,8 @@ static void refresh_env() {
     g_env.chain = geti("SD_CHAIN", 0);                // 1: in-order chained launch, 2: persistent engine (both measured slower)
     g_env.fuse_embed_qkv = geti("SD_FUSE_EMBED_QKV", 1);
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
+    g_env.attn_split_keys = geti("SD_ATTN_SPLIT_KEYS", 384);          // keys per workgroup above which a group's keys are split
+    g_env.attn_keys_per_split = std::max(16, geti("SD_ATTN_KEYS_PER_SPLIT", 256));
 }
 
 static int gemm_ntw(int N, int M) {
@@ -731,8 +735,7 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
         *s_cap = (int)align_up(keys, 64);
         return sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * *s_cap);
     };
-    static const int split_keys = getenv("SD_ATTN_SPLIT_KEYS") ? atoi(getenv("SD_ATTN_SPLIT_KEYS")) : ATT_SPLIT_KEYS;
-    static const int keys_per = getenv("SD_ATTN_KEYS_PER_SPLIT") ? atoi(getenv("SD_ATTN_KEYS_PER_SPLIT")) : 256;
+    const int split_keys = g_env.attn_split_keys, keys_per = g_env.attn_keys_per_split;
     int nsplit = 1, s_cap;
     if (s_max > split_keys) {
         nsplit = std::min(8, (s_max + keys_per - 1) / keys_per);
@@ -1284,11 +1287,29 @@ static int launch_attn_bf16(sd_session *s, const bf16_t *q, const RowTab &tab, i
 }
 
 static int run_forward(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits, void *stream) {
+    int rc;
     if (s->m->cfg.dtype == SD_BF16)
-        return forward_impl<bf16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
-    if (s->m->cfg.dtype == SD_F16)
-        return forward_impl<f16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
-    return forward_impl<float>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+        rc = forward_impl<bf16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+    else if (s->m->cfg.dtype == SD_F16)
+        rc = forward_impl<f16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+    else
+        rc = forward_impl<float>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
+    if (rc == SD_OK && s->chain_used) {
+        // The chained launches (SD_CHAIN=1|2, experimental, off by default) bound every device-side wait; a wait that ran
+        // into its limit carried on with stale operands and left a bit in the status word.  Such a forward must not hand
+        // its logits back: the status is read here (one stream sync, acceptable for an experimental mode) and a non-zero
+        // word fails the call.
+        unsigned status = 0;
+        SD_HIP_CHECK(hipMemcpyAsync(&status, s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS, sizeof(unsigned),
+                                    hipMemcpyDeviceToHost, (hipStream_t)stream));
+        SD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        if (status != 0) {
+            sd_set_error("chained layer launch (SD_CHAIN=%d): a phase wait hit its time limit (status %#x); the forward's "
+                         "results are invalid - rerun with SD_CHAIN=0", g_env.chain, status);
+            return SD_ERR_HIP;
+        }
+    }
+    return rc;
 }
 
 extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_new, int pos0, int n_logits,
@@ -1683,6 +1704,30 @@ extern "C" int sd_spec_iteration(sd_spec *sp, int L, int draft_len, int target_l
     return SD_OK;
 }
 
+// In-loop failure handling of the two native loops: every failure sets `rc` and leaves the loop, so the common epilogue
+// (event destruction, write-back of the in/out cursor state) always runs.
+#define SD_LOOP_HIP(expr)                                                                                   \
+    if (hipError_t _e = (expr); _e != hipSuccess) {                                                         \
+        sd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);          \
+        rc = SD_ERR_HIP;                                                                                    \
+        break;                                                                                              \
+    }
+// Waits for `ev` by polling (a blocking wait parks the thread, and the launches of the next iteration's draft steps - which
+// the GPU consumes as fast as they arrive - then start from a cold core); bounded in wall-clock time.
+static int poll_event(hipEvent_t ev, const char *who) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return SD_OK;
+        if (q != hipErrorNotReady) { sd_set_error("%s: %s", who, hipGetErrorString(q)); return SD_ERR_HIP; }
+        if ((spins & 0xfff) == 0xfff &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) {
+            sd_set_error("%s: the iteration's result did not arrive within 60 s", who);
+            return SD_ERR_HIP;
+        }
+    }
+}
+
 // The device-RNG loop without the interpreter between iterations (reference speculative_sampling.py:1934-2046).
 extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int T, int eos_token_id, int ori_eos_cnt,
                                 uint64_t *seed_io, uint64_t *draw_io, uint64_t random_seed, const float *r_const,
@@ -1709,19 +1754,13 @@ extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int
         if ((rc = sd_spec_iteration(sp, L, draft_len, target_len, seed_draft, d_draft, seed, d_scan, d_res, r_const, res_host,
                                     nullptr, stream)) != SD_OK)
             break;
-        // wait for the result block by polling an event (a blocking wait parks the thread, and the launches of the next
-        // iteration's draft steps - which the GPU consumes as fast as they arrive - then start from a cold core)
-        SD_HIP_CHECK(hipEventRecord(sp->ev_done, (hipStream_t)stream));
-        for (;;) {
-            const hipError_t q = hipEventQuery(sp->ev_done);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) { sd_set_error("sd_spec_generate: %s", hipGetErrorString(q)); return SD_ERR_HIP; }
-        }
+        SD_LOOP_HIP(hipEventRecord(sp->ev_done, (hipStream_t)stream));
+        if ((rc = poll_event(sp->ev_done, "sd_spec_generate")) != SD_OK) break;
         const sd_accept_result r = *res_host;
         if (r.flags & 2) { *err_out = 1; break; }
         if (r.flags & 8) {                                        // which word: a draft sample error, or a norm error
             std::vector<int> ew(3 * g + 1);
-            SD_HIP_CHECK(hipMemcpy(ew.data(), sp->err, sizeof(int) * ew.size(), hipMemcpyDeviceToHost));
+            SD_LOOP_HIP(hipMemcpy(ew.data(), sp->err, sizeof(int) * ew.size(), hipMemcpyDeviceToHost));
             bool samp = false;
             for (int i = g; i < 2 * g; ++i) samp = samp || ew[i] != 0;
             *err_out = samp ? 1 : 2;
@@ -1729,8 +1768,8 @@ extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int
         }
         if (sp->timing && (draft_ms_out || target_ms_out)) {
             float dms = 0.f, tms = 0.f;
-            SD_HIP_CHECK(hipEventElapsedTime(&dms, sp->ev[0], sp->ev[1]));
-            SD_HIP_CHECK(hipEventElapsedTime(&tms, sp->ev[2], sp->ev[3]));
+            SD_LOOP_HIP(hipEventElapsedTime(&dms, sp->ev[0], sp->ev[1]));
+            SD_LOOP_HIP(hipEventElapsedTime(&tms, sp->ev[2], sp->ev[3]));
             if (draft_ms_out) draft_ms_out[iters] = dms;
             if (target_ms_out) target_ms_out[iters] = tms;
         }
@@ -1741,7 +1780,11 @@ extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int
             if (q_at_out) q_at_out[(size_t)iters * g + i] = r.q_at[i];
         }
         ++iters;
-        SD_REQUIRE(n >= L - 1 && l >= 0 && l <= g, "sd_spec_generate: inconsistent result block (n %d, L %d, accepted %d)", n, L, l);
+        if (!(n >= L - 1 && l >= 0 && l <= g)) {
+            sd_set_error("sd_spec_generate: inconsistent result block (n %d, L %d, accepted %d)", n, L, l);
+            rc = SD_ERR_INVALID;
+            break;
+        }
         for (int i = 0; i < l; ++i) host_seq[len++] = r.drafted[i];
         host_seq[len++] = r.next_token;
         draft_len = std::min(L + g - 1, n + 1);                   // rollback(n + 1) of both caches (:2000, :2015 / 2023)
@@ -1772,9 +1815,13 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
     const int g = gamma, n_err = 3 * g + 1;
     const int max_verify = std::max(1, max_rows_per_forward / (g + 1));        // streams per target pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
-    SD_HIP_CHECK(hipEventCreate(&ev0));
-    SD_HIP_CHECK(hipEventCreate(&ev1));
-    SD_HIP_CHECK(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess) {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        sd_set_error("sd_spec_batch_generate: hipEventCreate failed");
+        return SD_ERR_HIP;
+    }
     *err_out = 0;
     int iters = 0, rc = SD_OK;
     std::vector<sd_batch_stream *> act;
@@ -1825,7 +1872,7 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
         }
         if (rc != SD_OK) break;
         // ---- verify: the uncached rows of every stream, max_verify streams per pass over the target weights
-        SD_HIP_CHECK(hipEventRecord(ev0, st));
+        SD_LOOP_HIP(hipEventRecord(ev0, st));
         for (int a0 = 0; a0 < n && rc == SD_OK; a0 += max_verify) {
             const int m = std::min(max_verify, n - a0);
             items.assign(m, sd_batch_item{});
@@ -1847,7 +1894,7 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
                                rows.data(), 0, norm_workspace, stream);
         }
         if (rc != SD_OK) break;
-        SD_HIP_CHECK(hipEventRecord(ev1, st));
+        SD_LOOP_HIP(hipEventRecord(ev1, st));
         // ---- accept scan + residual / bonus sample, all streams in two launches
         aitems.assign(n, sd_accept_item{});
         for (int j = 0; j < n; ++j) {
@@ -1864,15 +1911,10 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
         }
         const int res_mode = target_norm_mode == draft_norm_mode ? target_norm_mode : 0;
         if ((rc = sd_accept_batch(aitems.data(), n, ld, V, g, res_mode, stream)) != SD_OK) break;
-        SD_HIP_CHECK(hipMemcpyAsync(streams[0].res_host, streams[0].res_dev, sizeof(sd_accept_result) * (size_t)n_streams,
-                                    hipMemcpyDeviceToHost, st));
-        SD_HIP_CHECK(hipEventRecord(ev_done, st));
-        for (;;) {                                                // poll (see sd_spec_generate)
-            const hipError_t qe = hipEventQuery(ev_done);
-            if (qe == hipSuccess) break;
-            if (qe != hipErrorNotReady) { sd_set_error("sd_spec_batch_generate: %s", hipGetErrorString(qe)); rc = SD_ERR_HIP; break; }
-        }
-        if (rc != SD_OK) break;
+        SD_LOOP_HIP(hipMemcpyAsync(streams[0].res_host, streams[0].res_dev, sizeof(sd_accept_result) * (size_t)n_streams,
+                                   hipMemcpyDeviceToHost, st));
+        SD_LOOP_HIP(hipEventRecord(ev_done, st));
+        if ((rc = poll_event(ev_done, "sd_spec_batch_generate")) != SD_OK) break;
         if (iters < max_iters_log) {
             float ms = 0.f;
             if (verify_ms_out && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) verify_ms_out[iters] = ms;

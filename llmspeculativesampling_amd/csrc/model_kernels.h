@@ -1088,12 +1088,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 for (int k = 1; k < SREG; ++k) m0 = fmaxf(m0, v[k]);
                 half_maxes(m0, lo, hi);
                 m = half ? (upper ? hi : lo) : fmaxf(lo, hi);
+                // a tree row whose key chunk holds no visible key (split attention): every score is -inf; exp(-inf - 0)
+                // = 0 leaves zeros and (m, sum) = (-inf, 0), which attn_combine_kernel skips - not exp(-inf + inf) = NaN
+                const float mz = TREE && m == -INFINITY ? 0.f : m;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int k = 0; k < SREG; ++k) {
                     const int s = lane + k * LW;
                     if (s < len) {
-                        v[k] = expf(v[k] - m);
+                        v[k] = expf(v[k] - mz);
                         if (half && (k & 1)) s1 += v[k]; else s0 += v[k];
                     } else v[k] = 0.f;
                 }
@@ -1119,14 +1122,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 for (int s = lane; s < len; s += 32) m0 = fmaxf(m0, row[s]);
                 half_maxes(m0, lo, hi);
                 m = upper ? hi : lo;
+                const float mz = TREE && m == -INFINITY ? 0.f : m;
                 float s0 = 0.f, s1 = 0.f;                         // what lanes l and l + 32 of a full wave accumulate
                 for (int s = lane; s < len; s += 64) {
-                    const float e = expf(row[s] - m);
+                    const float e = expf(row[s] - mz);
                     row[s] = e;
                     s0 += e;
                 }
                 for (int s = lane + 32; s < len; s += 64) {
-                    const float e = expf(row[s] - m);
+                    const float e = expf(row[s] - mz);
                     row[s] = e;
                     s1 += e;
                 }
@@ -1139,9 +1143,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
                 for (int s = lane; s < len; s += 64) m0 = fmaxf(m0, row[s]);
                 half_maxes(m0, lo, hi);
                 m = fmaxf(lo, hi);
+                const float mz = TREE && m == -INFINITY ? 0.f : m;
                 float s0 = 0.f;
                 for (int s = lane; s < len; s += 64) {
-                    const float e = expf(row[s] - m);
+                    const float e = expf(row[s] - mz);
                     row[s] = e;
                     s0 += e;
                 }

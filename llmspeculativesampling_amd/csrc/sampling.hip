@@ -1189,10 +1189,12 @@ extern "C" int sd_norm_probs_lists(const float *logits, int rows, int V, long ld
 
 // top_k_top_p_filter on its own (utils.py:152-179): out = logit where kept, -inf where dropped (out != logits).
 extern "C" int sd_topk_topp_filter(const float *logits, int rows, int V, long ld_in, int top_k, float top_p,
-                                   float *out, long ld_out, void *stream) {
+                                   int dtype_mode, float *out, long ld_out, void *stream) {
     SD_REQUIRE(logits && out && rows >= 0 && V > 0, "sd_topk_topp_filter: bad arguments");
+    SD_REQUIRE(dtype_mode == 0 || dtype_mode == SD_NORM_DT_BF16 || dtype_mode == SD_NORM_DT_F16,
+               "sd_topk_topp_filter: dtype_mode %d", dtype_mode);
     if (rows == 0) return SD_OK;
-    return launch_norm(logits, rows, V, ld_in, 1.0f, top_k, top_p, 0, out, ld_out, nullptr, false, nullptr, 0, 0, nullptr,
+    return launch_norm(logits, rows, V, ld_in, 1.0f, top_k, top_p, dtype_mode, out, ld_out, nullptr, false, nullptr, 0, 0, nullptr,
                        nullptr, nullptr, stream, nullptr, 1);
 }
 

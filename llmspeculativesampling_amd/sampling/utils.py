@@ -49,7 +49,9 @@ def top_k_top_p_filter(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0)
     x = _rows_f32(logits)
     rows, V = x.shape
     out = torch.empty_like(x)
-    check(lib.sd_topk_topp_filter(x.data_ptr(), rows, V, x.stride(0), int(top_k or 0), float(top_p or 0.0),
+    # a 16-bit tensor is sorted / softmaxed / cumsummed in its own dtype by the reference (utils.py:170-172): same mode
+    # switch as norm_logits, so the kept set at the top-p cut is decided on the same 16-bit sums
+    check(lib.sd_topk_topp_filter(x.data_ptr(), rows, V, x.stride(0), int(top_k or 0), float(top_p or 0.0), _mode(logits),
                                   out.data_ptr(), out.stride(0), _stream()), "sd_topk_topp_filter")
     logits.masked_fill_(out == float("-inf"), float("-inf"))
     return logits

@@ -751,6 +751,41 @@ def g7_multi():
     print("G7:", len(cases), "multi traces")
 
 
+def g10_filter_lowprec():
+    """top_k_top_p_filter called directly on bf16 / fp16 rows (reference utils.py:152-179): the reference sorts, softmaxes
+    and cumsums in the tensor's dtype, so the kept set near the top-p cut is decided on 16-bit sums (the
+    stand-alone filter had no dtype mode; G8 only covered it through norm_logits).  Records the kept indices;
+    `tie_sensitive` as in G8."""
+    import oracle.sampling_ref as SR
+    cases, blobs = [], {}
+    cid = 0
+    for V in (32000, 50272, 4096):
+        for (k, p) in [(20, 0.9), (50, 0.95), (0, 0.8), (64, 0.99), (5, 0.0), (0, 0.5)]:
+            for dtype in (torch.bfloat16, torch.float16):
+                seed = 2600 + cid
+                x = logits_row(seed, V, dtype=dtype)
+                out = ref_utils.top_k_top_p_filter(x.clone(), top_k=k, top_p=p)
+                assert out.dtype == dtype and torch.equal(oracle.top_k_top_p_filter(x.clone(), k, p), out)
+                SR.STABLE_TIES = True
+                try:
+                    st = oracle.top_k_top_p_filter(x.clone(), k, p)
+                finally:
+                    SR.STABLE_TIES = False
+                kept = np.nonzero(torch.isfinite(out[0]).numpy())[0].astype(np.int32)
+                # the fp32 run of the same (16-bit-valued) row: where it keeps a different set the dtype mode matters
+                k32 = np.nonzero(torch.isfinite(ref_utils.top_k_top_p_filter(x.float().clone(), top_k=k, top_p=p)[0]).numpy())[0]
+                key = f"f{cid}"
+                blobs[key + "_kept"] = kept
+                cases.append(dict(id=key, seed=seed, V=V, scale=4.0, k=k, p=p, dtype=str(dtype).split(".")[1],
+                                  n_kept=int(kept.size), differs_from_fp32=bool(k32.size != kept.size or (k32 != kept).any()),
+                                  tie_sensitive=not torch.equal(st, out)))
+                cid += 1
+    np.savez_compressed(os.path.join(HERE, "g10_filter_lowprec.npz"), **blobs)
+    json.dump(cases, open(os.path.join(HERE, "g10_filter_lowprec.json"), "w"), indent=0)
+    print("G10:", len(cases), "rows; kept set differs from the fp32 run in", sum(c["differs_from_fp32"] for c in cases),
+          "; tie-sensitive", sum(c["tie_sensitive"] for c in cases))
+
+
 def misc():
     """Facts the design leans on, recorded from the live reference environment."""
     facts = {"torch": torch.__version__, "transformers": transformers.__version__}
@@ -765,7 +800,7 @@ def misc():
 
 
 if __name__ == "__main__":
-    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi, g8=g8_lowprec, g9=g9_tree)
+    todo = dict(misc=misc, g1=g1_norm_logits, g2=g2_sample_maxfn, g4=g4_accept, g5=g5_traces, g6=g6_logits, g7=g7_multi, g8=g8_lowprec, g9=g9_tree, g10=g10_filter_lowprec)
     for name in (sys.argv[1:] or list(todo)):             # e.g. `make_golden.py g7` regenerates one fixture set
         todo[name]()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))

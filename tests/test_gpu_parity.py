@@ -1108,3 +1108,29 @@ def test_lowprec_accept_resample_kernels_golden(hip, case):
         assert acc_len == case["acc_len"]
     else:
         assert all(0 <= t < V for t in host)
+
+
+# --------------------------------------------------------------------------- G10: the stand-alone filter on 16-bit rows
+G10_META, G10 = load("g10_filter_lowprec")
+
+
+@pytest.mark.parametrize("case", G10_META, ids=[c["id"] for c in G10_META])
+def test_lowprec_top_k_top_p_filter_golden(hip, case):
+    """sampling.utils.top_k_top_p_filter on a bf16 / fp16 tensor (sd_topk_topp_filter with its dtype mode):
+    in place, returns its argument, and keeps exactly the set the reference kept (reference utils.py:152-179 run in the
+    row dtype) - up to the reference's unspecified order inside a run of equal logits at the top-p cut."""
+    dt = DT[case["dtype"]]
+    x = logits_row(case["seed"], case["V"], case["scale"], dtype=dt)
+    xd = x.cuda()
+    y = hip.S.top_k_top_p_filter(xd, case["k"], case["p"])
+    assert y is xd and y.dtype == dt
+    g = y.float().cpu().numpy()[0]
+    kept = np.nonzero(np.isfinite(g))[0]
+    want = G10[case["id"] + "_kept"]
+    z = x.float().numpy()[0]
+    np.testing.assert_array_equal(g[kept], z[kept])              # kept logits are untouched
+    if not case["tie_sensitive"]:
+        np.testing.assert_array_equal(kept, want)
+    else:
+        assert len(kept) == len(want)
+        np.testing.assert_array_equal(np.sort(z[kept]), np.sort(z[want]))     # same logit multiset: twins at the cut

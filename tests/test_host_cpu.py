@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.sd_version() == 2           # a host-only call: no GPU needed
+    assert _lib.lib.sd_version() == 3           # a host-only call: no GPU needed
 
 
 def test_struct_layouts_match_header():

@@ -338,3 +338,20 @@ def test_acceptance_count_recursion_golden(case):
     np.testing.assert_allclose(prob.numpy(), G9[case["id"] + "_prob"], atol=1e-6)
     assert abs(float(expect) - case["expect"]) < 1e-5
     assert [tree_ref.get_expect_cnt_by_thres(prob, th) for th in case["thres"]] == case["counts"]
+
+
+# --------------------------------------------------------------------------- G10: the stand-alone filter on 16-bit rows
+G10_META, G10 = load("g10_filter_lowprec")
+
+
+@pytest.mark.parametrize("case", G10_META, ids=[c["id"] for c in G10_META])
+def test_lowprec_top_k_top_p_filter_golden(case):
+    """top_k_top_p_filter on bf16 / fp16 rows (reference utils.py:152-179 sorts / softmaxes / cumsums in the row dtype):
+    the kept set recorded from the reference, which for 6 of the 36 rows is not the set an fp32 run keeps."""
+    dt = DT[case["dtype"]]
+    x = logits_row(case["seed"], case["V"], case["scale"], dtype=dt)
+    out = oracle.top_k_top_p_filter(x.clone(), case["k"], case["p"])
+    assert out.dtype == dt
+    kept = np.nonzero(torch.isfinite(out[0]).numpy())[0]
+    np.testing.assert_array_equal(kept, G10[case["id"] + "_kept"])
+    assert torch.equal(out[0][kept], x[0][kept])                 # kept logits are untouched
