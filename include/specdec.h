@@ -427,6 +427,21 @@ int sd_tp_create_loopback(int world, sd_tp **out /* world handles */);
 int sd_tp_destroy(sd_tp *t);
 int sd_session_set_tp(sd_session *s, sd_tp *t);
 
+/* ------------------------------------------------------------------------------------------
+ * Throughput-mode gather: prompt streams are sharded over the ranks (stream s on rank s mod
+ * world) and never talk inside the decode loop; at the end every rank contributes its packed token rows
+ * [rows][width] int32 (-1 padded) and receives all ranks' rows, [world][rows][width], through ONE ncclAllGather over
+ * RCCL / xGMI (KB-scale: latency-bound).  The reference has no counterpart (single process, evaluation.py:524-532 reads
+ * the output of its one stream); `sd_comm_unique_id` is ncclGetUniqueId, whose 128 bytes the host hands to every rank
+ * (torch.distributed's store / broadcast, or any side channel).  send / recv are device buffers of this rank's GPU.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sd_comm sd_comm;
+int sd_comm_unique_id(void *id128);
+int sd_comm_init(int rank, int world, const void *id128, sd_comm **out);
+int sd_comm_all_gather_tokens(sd_comm *c, const int32_t *send, int32_t *recv, int rows, int width, void *stream);
+int sd_comm_rank(const sd_comm *c, int *rank_out, int *world_out);
+int sd_comm_destroy(sd_comm *c);
+
 /* Per-op-class timing for the roofline report: when enabled, every launch inside
  * sd_session_forward is bracketed with HIP events on the launch stream; sd_profile_read
  * synchronises the stream, returns accumulated milliseconds and launch counts per class, and

@@ -131,6 +131,11 @@ SYMBOLS = [
     ("sd_tp_create_loopback", _I, [_I, C.POINTER(_VP)]),
     ("sd_tp_destroy", _I, [_VP]),
     ("sd_session_set_tp", _I, [_VP, _VP]),
+    ("sd_comm_unique_id", _I, [_VP]),
+    ("sd_comm_init", _I, [_I, _I, _VP, C.POINTER(_VP)]),
+    ("sd_comm_all_gather_tokens", _I, [_VP, _VP, _VP, _I, _I, _VP]),
+    ("sd_comm_rank", _I, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("sd_comm_destroy", _I, [_VP]),
     ("sd_profile_enable", _I, [_VP, _I]),
     ("sd_profile_read", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 ]

@@ -510,7 +510,9 @@ typedef int (*nccl_getid_fn)(void *);
 struct sd_nccl_id { char b[128]; };                  // ncclUniqueId is passed by value
 typedef int (*nccl_initrank_fn)(void **, int, sd_nccl_id, int);
 typedef int (*nccl_destroy_fn)(void *);
-static struct { void *lib; nccl_allreduce_fn allreduce; nccl_getid_fn getid; nccl_initrank_fn initrank; nccl_destroy_fn destroy; } g_rccl;
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+static struct { void *lib; nccl_allreduce_fn allreduce; nccl_getid_fn getid; nccl_initrank_fn initrank; nccl_destroy_fn destroy;
+                nccl_allgather_fn allgather; } g_rccl;
 
 static int rccl_load() {
     if (g_rccl.lib) return SD_OK;
@@ -522,8 +524,9 @@ static int rccl_load() {
     g_rccl.getid = (nccl_getid_fn)dlsym(h, "ncclGetUniqueId");
     g_rccl.initrank = (nccl_initrank_fn)dlsym(h, "ncclCommInitRank");
     g_rccl.destroy = (nccl_destroy_fn)dlsym(h, "ncclCommDestroy");
-    if (!g_rccl.allreduce || !g_rccl.getid || !g_rccl.initrank || !g_rccl.destroy) {
-        sd_set_error("RCCL is missing ncclAllReduce / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy");
+    g_rccl.allgather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
+    if (!g_rccl.allreduce || !g_rccl.getid || !g_rccl.initrank || !g_rccl.destroy || !g_rccl.allgather) {
+        sd_set_error("RCCL is missing ncclAllReduce / ncclAllGather / ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy");
         return SD_ERR_HIP;
     }
     g_rccl.lib = h;
@@ -548,6 +551,46 @@ extern "C" int sd_tp_create_rccl(int rank, int world, const void *id128, sd_tp *
     if (g_rccl.initrank(&comm, world, id, rank) != 0) { sd_set_error("ncclCommInitRank(rank %d of %d) failed", rank, world); return SD_ERR_HIP; }
     sd_tp *t = new sd_tp{rank, world, comm, nullptr};
     *out = t;
+    return SD_OK;
+}
+
+// ---- throughput-mode gather of the sharded streams' token rows: one ncclAllGather over RCCL / xGMI ----
+struct sd_comm { int rank, world; void *comm; };
+
+extern "C" int sd_comm_unique_id(void *id128) { return sd_tp_unique_id(id128); }
+
+extern "C" int sd_comm_init(int rank, int world, const void *id128, sd_comm **out) {
+    SD_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, "sd_comm_init: bad arguments");
+    int rc = rccl_load();
+    if (rc != SD_OK) return rc;
+    sd_nccl_id id;
+    memcpy(id.b, id128, 128);
+    void *comm = nullptr;
+    if (g_rccl.initrank(&comm, world, id, rank) != 0) { sd_set_error("ncclCommInitRank(rank %d of %d) failed", rank, world); return SD_ERR_HIP; }
+    *out = new sd_comm{rank, world, comm};
+    return SD_OK;
+}
+
+extern "C" int sd_comm_all_gather_tokens(sd_comm *c, const int32_t *send, int32_t *recv, int rows, int width, void *stream) {
+    SD_REQUIRE(c && send && recv && rows >= 0 && width >= 1, "sd_comm_all_gather_tokens: bad arguments");
+    if (rows == 0) return SD_OK;
+    if (g_rccl.allgather(send, recv, (size_t)rows * (size_t)width, /* ncclInt32 */ 2, c->comm, (hipStream_t)stream) != 0) {
+        sd_set_error("ncclAllGather of %d x %d token rows failed on rank %d of %d", rows, width, c->rank, c->world);
+        return SD_ERR_HIP;
+    }
+    return SD_OK;
+}
+
+extern "C" int sd_comm_rank(const sd_comm *c, int *rank_out, int *world_out) {
+    SD_REQUIRE(c && rank_out && world_out, "sd_comm_rank: null argument");
+    *rank_out = c->rank; *world_out = c->world;
+    return SD_OK;
+}
+
+extern "C" int sd_comm_destroy(sd_comm *c) {
+    if (!c) return SD_OK;
+    if (c->comm && g_rccl.destroy) g_rccl.destroy(c->comm);
+    delete c;
     return SD_OK;
 }
 

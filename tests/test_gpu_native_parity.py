@@ -855,8 +855,7 @@ def test_tree_attention_wide_tree_16bit_vs_oracle(hip, dtype, kv_dtype):
 def test_tree_attention_split_keys_chunk_without_visible_key(hip):
     """with the keys of a group cut over several workgroups, a chunk can hold only tree rows a node may not
     see (every score -inf).  Its partial must be (zeros, m = -inf, l = 0) - what attn_combine_kernel skips - not
-    exp(-inf + inf) = NaN.  150 cached keys + 40 tree nodes in 32-key chunks: the last chunk is all tree rows.  The split
-    result must equal the unsplit one up to the fp32 re-association of the combine."""
+    exp(-inf + inf) = NaN.  150 cached keys + 40 tree nodes in 32-key chunks: the last chunk is all tree rows."""
     from test_gpu_parity import MID_CFGS
     cfg = ModelConfig(**MID_CFGS["llama_d64_gqa"])
     sd = make_state_dict(cfg, 77, dtype=torch.bfloat16, gain=0.7)
@@ -879,5 +878,10 @@ def test_tree_attention_split_keys_chunk_without_visible_key(hip):
             os.environ.pop("SD_ATTN_SPLIT_KEYS", None)
             os.environ.pop("SD_ATTN_KEYS_PER_SPLIT", None)
     assert bool(torch.isfinite(outs[1]).all())
-    tv = 0.5 * (outs[0] - outs[1]).abs().sum(-1)
-    assert float(tv.max()) <= 0.02, float(tv.max())
+    # split attention keeps un-rounded exp() weights until the combine, the one-workgroup form rounds the probabilities to
+    # bf16 first (as the reference does): both are held to the oracle's bf16 tree forward under the wide-tree test's bar
+    okv = oracle.RefKVCacheModel(oracle.RefCausalLM(cfg, sd), 1, 20, 0.9)
+    want = okv.forward_tree_attention(seq, prompt, mask, pids, pos.clone()).float()
+    for o in outs:
+        tv = 0.5 * (o - want).abs().sum(-1)
+        assert float(tv.max()) <= 0.05, float(tv.max())
