@@ -51,9 +51,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-max-len", type=int, default=32)
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="wall budget for the CPU baseline runs")
     ap.add_argument("--cpu-prompt-len", type=int, default=128)
-    ap.add_argument("--batch-streams", type=int, default=1,
+    ap.add_argument("--batch-streams", "--streams-per-gpu", dest="batch_streams", type=int, default=1,
                     help="throughput mode (SURVEY 8(f)): this many prompt streams decode in lockstep per step and share every "
-                         "weight pass (speculative_sampling_batch); 1 = the single-stream path of BASELINE configs[1]")
+                         "weight pass (speculative_sampling_batch); 1 = the single-stream path of BASELINE configs[1].  "
+                         "BASELINE configs[3] (64 streams over 8 GPUs) is `--gpus 8 --streams-per-gpu 8 --steps 1`")
     ap.add_argument("--profile-classes", type=int, default=1, help="per-op-class HIP-event timing of one verify step")
     ap.add_argument("--accept-sweep", type=int, default=1,
                     help="after the headline, time the same workload on the acceptance-dial pair at each --sweep-sigmas (N=1)")
@@ -141,6 +142,22 @@ def algorithmic_verify_bytes(cfg, gamma, S, wbytes=2, kvbytes=2):
     return w + kv_row * S + kv_row * (gamma + 1) + (gamma + 1) * cfg.vocab_size * 4
 
 
+def find_checkpoint(name):
+    """$SPECDEC_MODEL_DIR/<name> (also the hub-style spellings of the BASELINE pairs) if it is a local HF checkpoint
+    directory; None otherwise.  Nothing is ever fetched."""
+    root = os.environ.get("SPECDEC_MODEL_DIR")
+    if not root:
+        return None
+    alts = [name, name.replace("llama-2-", "Llama-2-"), name.replace("llama-2-", "Llama-2-") + "-hf",
+            os.path.join("JackFram", name), os.path.join("meta-llama", name.replace("llama-2-", "Llama-2-") + "-hf"),
+            os.path.join("facebook", name)]
+    for a in alts:
+        d = os.path.join(root, a)
+        if os.path.isfile(os.path.join(d, "config.json")):
+            return d
+    return None
+
+
 def prompt_for(stream, V, L):
     g = torch.Generator().manual_seed(1000 + stream)
     return torch.randint(3, V, (1, L), generator=g)
@@ -178,8 +195,8 @@ def cpu_baseline(args, dcfg, tcfg, dm, tm):
     ncores = host_cpu_share()
     torch.set_num_threads(ncores)
     t0 = time.time()
-    dsd = {n: dm._synth_get(n).cpu() for n in dm._synth_names}
-    tsd = {n: tm._synth_get(n).cpu() for n in tm._synth_names}
+    dsd = {n: dm._synth_get(n).cpu().to(torch.bfloat16) for n in dm._synth_names}      # (a checkpoint may be stored in fp16)
+    tsd = {n: tm._synth_get(n).cpu().to(torch.bfloat16) for n in tm._synth_names}
     for sd in (dsd, tsd):
         if "model.decoder.embed_tokens.weight" in sd:
             sd["lm_head.weight"] = sd["model.decoder.embed_tokens.weight"]
@@ -223,7 +240,7 @@ def cpu_baseline(args, dcfg, tcfg, dm, tm):
     per_iter_txt = f"{r['per_iter']:.2f} s per draft+verify iteration after the prefill; " if r["per_iter"] else ""
     return {
         "value": r["new"] / r["wall"], "unit": "tokens/s", "cores": ncores, "kind": "port",
-        "sample": (f"oracle.speculative_sampling (torch-CPU restatement), same random-init bf16 weights as the GPU run, "
+        "sample": (f"oracle.speculative_sampling (torch-CPU restatement), the same bf16 weights as the GPU run, "
                    f"prompt {args.cpu_prompt_len}, max_len {r['n_tok']} (the GPU run uses max_len {args.max_len}), gamma "
                    f"{args.gamma}: {r['new']} tokens in {r['wall']:.1f} s wall / {r['cpu']:.1f} s process_time over "
                    f"{r['iters']} iterations incl. both prefills; {per_iter_txt}weight copy {t_copy:.1f} s not timed"),
@@ -317,8 +334,16 @@ def main(argv=None):
     dcfg, tcfg = load_config(args.draft), load_config(args.target)
     max_pos = args.prompt_len + args.max_len + args.gamma + 8
     t0 = time.time()
-    dm = SpecDecModel.synthetic(dcfg, seed=1, dtype=torch.bfloat16, max_pos=max_pos)
     TP = args.tp
+    # real checkpoints from a LOCAL directory when SPECDEC_MODEL_DIR holds them (never the hub), else
+    # random-init from the committed config JSONs (accept-len ~0 by construction; `data` says which)
+    ckpt_d, ckpt_t = find_checkpoint(args.draft), find_checkpoint(args.target)
+    use_ckpt = bool(ckpt_d and ckpt_t and TP == 1)
+    if use_ckpt:
+        dm = SpecDecModel.from_pretrained_dir(ckpt_d, dtype=torch.bfloat16, max_pos=max_pos)
+        dcfg = dm.cfg
+    else:
+        dm = SpecDecModel.synthetic(dcfg, seed=1, dtype=torch.bfloat16, max_pos=max_pos)
     if TP > 1:
         # config 5: the target is ONE model sharded over all ranks (two RCCL all-reduces per layer); every rank runs the
         # same stream with the same RNG seed, the draft is replicated
@@ -331,6 +356,9 @@ def main(argv=None):
             return box[0]
         group = tpmod.TPGroup.rccl(rank, world, bcast)
         tm = tpmod.synthetic_shard(tcfg, rank, world, seed=2, group=group, dtype=torch.bfloat16, max_pos=max_pos)
+    elif use_ckpt:
+        tm = SpecDecModel.from_pretrained_dir(ckpt_t, dtype=torch.bfloat16, max_pos=max_pos)
+        tcfg = tm.cfg
     else:
         tm = SpecDecModel.synthetic(tcfg, seed=2, dtype=torch.bfloat16, max_pos=max_pos)
     if args.kv_dtype == "fp8":
@@ -485,12 +513,15 @@ def main(argv=None):
         "metric": "accepted tokens/sec (speculative_sampling, llama-68m -> Llama-2-13b, gamma=4)",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if TP == 1 else "strong",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "scaling_note": None if TP == 1 else
+        "vs_baseline": None, "dtype": "bf16",
+        "data": "checkpoint" if use_ckpt else "synthetic", "scaling_note": None if TP == 1 else
         "tensor-parallel target: the ranks decode the SAME stream together (strong scaling of one stream), per-rank roofline",
         "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt {args.prompt_len}, "
                                f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, {BS} stream(s) per step per GPU"
                                f"{' decoded in lockstep through shared weight passes' if BS > 1 else ''}, "
-                               f"rng={args.rng}; random-init weights (accept-len ~0 by construction)",
+                               f"rng={args.rng}; " + (f"local checkpoints {ckpt_d} -> {ckpt_t}, synthetic prompts" if use_ckpt else
+                                                      "random-init weights (accept-len ~0 by construction)") +
+                               ("; mode: throughput (stream-batched verify)" if BS > 1 else "; mode: single stream (BASELINE configs[1])"),
                    "streams": args.steps * (1 if TP > 1 else world) * BS,
                    "parallelism": (f"streams sharded over {world} GPU(s), no data-path collective" if TP == 1 else
                                    f"target tensor-parallel over {TP} GPUs (2 RCCL all-reduces per layer), draft replicated"),
@@ -499,7 +530,8 @@ def main(argv=None):
         "roofline": roofline, "model_build_s": t_build,
     }
 
-    if args.accept_sweep and rank == 0 and world == 1 and BS == 1 and args.kv_dtype == "model" and dcfg.arch == "llama" and tcfg.arch == "llama":
+    if (args.accept_sweep and rank == 0 and world == 1 and BS == 1 and args.kv_dtype == "model" and dcfg.arch == "llama"
+            and tcfg.arch == "llama" and not use_ckpt):
         try:
             result["acceptance_sweep"] = acceptance_sweep(args, dcfg, tcfg, max_pos)
         except Exception as e:

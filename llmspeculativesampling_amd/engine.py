@@ -247,11 +247,82 @@ class SpecDecModel:
         m._synth_get, m._synth_names = get, list(shapes)     # lets a host baseline regenerate the same tensors
         return m
 
+    @classmethod
+    def from_pretrained_dir(cls, path: str, dtype=torch.bfloat16, device="cuda", max_pos=None) -> "SpecDecModel":
+        """A LOCAL HF checkpoint directory (config.json + *.safetensors or pytorch_model*.bin), read tensor by tensor with
+        loaders that execute nothing from the files (safetensors; torch.load(weights_only=True)) - never the hub
+        (the reference loads by hub name, evaluation.py:183-253; SURVEY.md 8(d): SPECDEC_MODEL_DIR)."""
+        cfg, get, names = checkpoint_getter(path)
+        m = cls(cfg, get, dtype=dtype, device=device, max_pos=max_pos)
+        m._synth_get, m._synth_names = get, names           # lets a host baseline read the same tensors
+        m.checkpoint = path
+        return m
+
     def new_session(self, max_seq: int, max_rows: int = MAX_PREFILL_ROWS, kv_dtype: Optional[str] = None) -> "Session":
         ses = Session(self, max_seq, max_rows, kv_dtype=kv_dtype or self.kv_dtype)
         if self.tp_group is not None:
             self.tp_group.bind(ses)
         return ses
+
+
+def checkpoint_getter(path: str):
+    """(ModelConfig, get(name) -> CPU tensor, names) for a local HF checkpoint directory.  Tied OPT heads are resolved the
+    way the reference's classes tie them (modeling_opt.py:833,840)."""
+    import glob
+    import json
+    import os
+    from types import SimpleNamespace
+    from .synth import param_shapes
+    with open(os.path.join(path, "config.json")) as f:
+        raw = json.load(f)
+    hf = SimpleNamespace(**raw)
+    if not hasattr(hf, "_name_or_path"):
+        hf._name_or_path = os.path.basename(os.path.normpath(path))
+    if getattr(hf, "model_type", "") == "opt":
+        for k, v in (("do_layer_norm_before", True), ("word_embed_proj_dim", raw.get("hidden_size"))):
+            if not hasattr(hf, k):
+                setattr(hf, k, v)
+    cfg = config_from_hf(hf)
+    where: Dict[str, tuple] = {}
+    st_files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if st_files:
+        from safetensors import safe_open
+        for fn in st_files:
+            with safe_open(fn, framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    where[k] = ("st", fn)
+    else:
+        for fn in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
+            sd = torch.load(fn, map_location="cpu", weights_only=True, mmap=True)
+            for k in sd:
+                where[k] = ("pt", fn)
+            del sd
+    if not where:
+        raise FileNotFoundError(f"{path}: no *.safetensors or pytorch_model*.bin")
+    cache: Dict[str, dict] = {}
+
+    def get(name: str) -> torch.Tensor:
+        key = name
+        if key not in where:
+            alts = [name.replace("model.decoder.", "decoder."), "model." + name]
+            if name == "lm_head.weight":
+                alts += ["model.decoder.embed_tokens.weight", "decoder.embed_tokens.weight", "model.embed_tokens.weight"]
+            key = next((a for a in alts if a in where), None)
+            if key is None:
+                raise KeyError(f"{path}: tensor {name!r} not in the checkpoint")
+        kind, fn = where[key]
+        if kind == "st":
+            from safetensors import safe_open
+            with safe_open(fn, framework="pt", device="cpu") as f:
+                return f.get_tensor(key)
+        if fn not in cache:
+            cache.clear()
+            cache[fn] = torch.load(fn, map_location="cpu", weights_only=True, mmap=True)
+        return cache[fn][key]
+    names = [n for n, _, _ in param_shapes(cfg)]
+    if cfg.arch == "opt":
+        names.append("lm_head.weight")
+    return cfg, get, names
 
 
 class Session:

@@ -141,4 +141,8 @@ def speculative_log_lines(title: str, total_ns: int, tokens: int, agg: dict, sco
             f"acc rate {np.mean(agg['acc_rate']) if agg['acc_rate'] else 0.0}, "
             f"approx call times {agg['approx_call_times']}",
             f"prob score = {np.mean(scores)}, prob score cut = {np.mean(scores)}",
-            f"total power consumption: {power}", f"power/token: {power / max(tokens, 1)}"]
+            f"total power consumption: {power}", f"power/token: {power / max(tokens, 1)}",
+            # evaluation.py:581-582 (the wrapper's forward_time_dict summed over the prompts, kvcache_model.py:163-250)
+            f"target_model_time: {agg.get('target_model_time', 0) / 1e9}, "
+            f"pre cache time: {agg.get('target_pre_cache_time', 0) / 1e9}, "
+            f"post prob time: {agg.get('target_post_prob_time', 0) / 1e9}"]

@@ -180,11 +180,13 @@ def test_harness_chatalpaca_reader_and_power_sum(tmp_path):
     assert all(d.shape[0] == 1 and 32 <= d.shape[1] <= 512 and int(d.min()) >= 3 and int(d.max()) < 1000 for d in ds)
     assert [d.shape[1] for d in ds] == [d.shape[1] for d in harness.synthetic_prompts(5, 1000)]
     agg = dict(approx_time=2e9, target_time=3e9, other_time=1e9, acc_len_sum=30.0, acc_rate=[0.5, 0.7],
-               target_call_times=10, approx_call_times=10)
+               target_call_times=10, approx_call_times=10, target_model_time=2.5e9, target_pre_cache_time=0.25e9,
+               target_post_prob_time=0.5e9)
     out = harness.speculative_log_lines("google speculative decoding (with KVCache)", int(6e9), 40, agg, [-1.0, -3.0], 90.0)
     assert "total time 6.0 s, total tokens 40, average time 0.15 s/token" in out[0]
     assert out[2].startswith("average accepted len 3.0, target call times 10, acc rate 0.6")
-    assert out[-1] == "power/token: 2.25"
+    assert out[-2] == "power/token: 2.25"
+    assert out[-1] == "target_model_time: 2.5, pre cache time: 0.25, post prob time: 0.5"      # evaluation.py:581
 
 
 def test_sampling_package_exports_every_reference_name():
@@ -374,4 +376,68 @@ def test_new_entry_points_reject_null_arguments_without_a_gpu():
     assert lib.sd_norm_probs_lists(None, 1, 32000, 32000, 1.0, 20, 0.9, 0, None, 32000, None, None, None, None) \
         == _lib.SD_ERR_INVALID
     assert lib.sd_session_chain_status(None, None) == _lib.SD_ERR_INVALID
+    # round 3: the RCCL gather of the sharded streams (sd_comm_*) and the filter's dtype mode
+    h = C.c_void_p()
+    assert lib.sd_comm_init(0, 1, None, C.byref(h)) == _lib.SD_ERR_INVALID and b"sd_comm_init" in lib.sd_last_error()
+    assert lib.sd_comm_init(2, 2, C.addressof((C.c_char * 128)()), C.byref(h)) == _lib.SD_ERR_INVALID      # rank outside the world
+    assert lib.sd_comm_all_gather_tokens(None, None, None, 1, 8, None) == _lib.SD_ERR_INVALID
+    assert lib.sd_comm_rank(None, C.byref(z), C.byref(z)) == _lib.SD_ERR_INVALID
+    assert lib.sd_comm_destroy(None) == _lib.SD_OK
+    buf = (C.c_float * 16)()
+    assert lib.sd_topk_topp_filter(C.addressof(buf), 1, 16, 16, 4, 0.9, 7, C.addressof(buf), 16, None) == _lib.SD_ERR_INVALID
+    assert b"dtype_mode" in lib.sd_last_error()
     assert lib.sd_cand_list_bytes(3) == 3 * (4 + 128 * 4 + 128 * 4) and lib.sd_cand_list_bytes(0) == 0
+
+
+def test_local_checkpoint_getter_and_bench_lookup(tmp_path, monkeypatch):
+    """SURVEY.md 8(d) / VERDICT r2: SPECDEC_MODEL_DIR.  A checkpoint directory written by save_pretrained is read tensor by
+    tensor through safetensors (nothing is executed from the files, nothing is fetched); bench.find_checkpoint resolves the
+    BASELINE names inside $SPECDEC_MODEL_DIR and returns None when the variable or the directory is absent."""
+    import transformers
+    import bench
+    from llmspeculativesampling_amd.engine import checkpoint_getter
+    torch.manual_seed(0)
+    lc = transformers.LlamaConfig(vocab_size=256, hidden_size=32, num_hidden_layers=2, intermediate_size=64,
+                                  num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=64,
+                                  tie_word_embeddings=False)
+    oc = transformers.OPTConfig(vocab_size=256, hidden_size=32, num_hidden_layers=1, ffn_dim=64, num_attention_heads=4,
+                                max_position_embeddings=64, do_layer_norm_before=True, word_embed_proj_dim=32)
+    for sub, mod in (("llama-68m", transformers.LlamaForCausalLM(lc)), ("facebook/opt-125m", transformers.OPTForCausalLM(oc))):
+        d = tmp_path / sub
+        d.mkdir(parents=True)
+        mod.save_pretrained(str(d))
+        cfg, get, names = checkpoint_getter(str(d))
+        sd = mod.state_dict()
+        assert cfg.hidden_size == 32 and cfg.vocab_size == 256
+        for n in names:
+            want = sd[n] if n in sd else sd["model.decoder.embed_tokens.weight"]       # tied OPT head
+            assert torch.equal(get(n), want), n
+    monkeypatch.delenv("SPECDEC_MODEL_DIR", raising=False)
+    assert bench.find_checkpoint("llama-68m") is None
+    monkeypatch.setenv("SPECDEC_MODEL_DIR", str(tmp_path))
+    assert bench.find_checkpoint("llama-68m") == str(tmp_path / "llama-68m")
+    assert bench.find_checkpoint("opt-125m") == str(tmp_path / "facebook" / "opt-125m")
+    assert bench.find_checkpoint("llama-2-13b") is None
+
+
+def test_host_code_under_address_sanitizer():
+    """SURVEY.md section 5 / VERDICT r2: a host-side -fsanitize=address configuration.  libspecdec's host C++ (argument
+    validation, struct hand-off, RCCL / loop plumbing reachable without a GPU) is rebuilt with AddressSanitizer
+    (_build.build_asan: host code only, ~12 s) and the ABI / argument tests of this file run against it in a child
+    interpreter with the sanitizer runtime preloaded; any report fails the child."""
+    import subprocess
+    if os.environ.get("SD_ASAN_CHILD"):
+        pytest.skip("already inside the sanitizer child")
+    from llmspeculativesampling_amd import _build
+    lib = _build.build_asan()
+    rt = _build.asan_runtime()
+    assert os.path.exists(lib) and os.path.exists(rt), (lib, rt)
+    env = dict(os.environ, LD_PRELOAD=rt, SD_LIBSPECDEC=lib, SD_ASAN_CHILD="1",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
+    sel = ("test_library_exports_every_declared_symbol or test_struct_layouts_match_header or "
+           "test_argument_errors_do_not_need_a_gpu or test_new_entry_points_reject_null_arguments_without_a_gpu")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out, out[-4000:]
+    assert r.returncode == 0 and "4 passed" in out, out[-4000:]

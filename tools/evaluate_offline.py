@@ -133,7 +133,7 @@ def main():
         for title, run in loops:
             total_ns = tokens = 0
             agg = dict(approx_time=0, target_time=0, other_time=0, acc_len_sum=0, acc_rate=[], target_call_times=0,
-                       approx_call_times=0)
+                       approx_call_times=0, target_model_time=0, target_pre_cache_time=0, target_post_prob_time=0)
             scores = []
             wall0 = time.time()
             with harness.PowerMonitor() as pm:
@@ -145,6 +145,8 @@ def main():
                     tokens += len(out[0]) - ids.size(1)
                     for k in ("approx_time", "target_time", "other_time", "target_call_times", "approx_call_times"):
                         agg[k] += d[k]
+                    for k in ("target_model_time", "target_pre_cache_time", "target_post_prob_time"):   # evaluation.py:540-542
+                        agg[k] += d.get(k, 0)
                     agg["acc_len_sum"] += float(np.sum(d["acc_len"]))
                     agg["acc_rate"].append(float(d["acc_rate"]))
                     scores.append(get_score(out, large, ids.size(1)).item())
