@@ -12,6 +12,7 @@
 #include "model_kernels.h"
 #include "small_kernels.h"
 #include "chain_kernels.h"
+#include "rows_kernels.h"
 
 static thread_local char g_err[512] = "";
 void sd_set_error(const char *fmt, ...) {
@@ -140,6 +141,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
+    int gemm_rows = 1, cus = 0;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -153,6 +155,14 @@ static void refresh_env() {
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
     g_env.attn_split_keys = geti("SD_ATTN_SPLIT_KEYS", 384);          // keys per workgroup above which a group's keys are split
     g_env.attn_keys_per_split = std::max(16, geti("SD_ATTN_KEYS_PER_SPLIT", 256));
+    g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
+    if (!g_env.cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_env.cus = n;
+        else
+            (void)hipGetLastError();                  // no device (CPU container): plans are made for the MI355X's 256 CUs
+    }
 }
 
 static int gemm_ntw(int N, int M) {
@@ -255,12 +265,64 @@ static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, 
                            Mpad, N, K, pl.S, pl.ksp);
 }
 
+// ---- 17..64 rows: the balanced one-workgroup-per-CU kernel (rows_kernels.h).  S k-slabs x NG n-groups = one workgroup per
+// CU; a fused epilogue needs S == 1.  The plan minimises (weight bytes + slab traffic) / how evenly the n-tiles divide.
+struct RowsPlan { bool ok; int S, ksp, NG, grid; };
+static RowsPlan rows_plan(int N, int K, int M, bool fused) {
+    RowsPlan p = {};
+    if (!g_env.gemm_rows || M <= 16 || M > 64 || N % 16 || K % 32) return p;
+    const int G = g_env.cus > 0 ? g_env.cus : 256, NT = N / 16, KS = K / 32, Mpad = (int)align_up(M, 16);
+    const double wbytes = (double)N * K * 2.0, slab = 2.0 * Mpad * (double)N * 4.0;
+    double best = 1e300;
+    for (int S = 1; S <= (fused ? 1 : 16); S *= 2) {
+        if (G % S || KS / S < 8) break;
+        const int NG = G / S, tpg = (NT + NG - 1) / NG;
+        if (NT < NG || tpg > GR_MAX_TILES) continue;
+        const double eff = (double)NT / NG / tpg;
+        const double cost = (wbytes + (fused ? 0.0 : slab * S)) / eff;
+        if (cost < best) {
+            best = cost;
+            p.S = S; p.NG = NG;
+            p.ksp = (KS + S - 1) / S;
+            p.ok = eff >= 0.8;
+        }
+    }
+    if (p.ok) { p.S = (KS + p.ksp - 1) / p.ksp; p.grid = p.NG * p.S; }
+    return p;
+}
+
+template <int EPI, typename H>
+static int launch_gemm_rows(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, const RowsPlan &pl,
+                            const GemmEpiT<H> &e, hipStream_t st) {
+    const int MT = Mpad / 16;
+    const size_t lds = (size_t)16 * 1024 * MT;                    // activation ring == fold buffer: 16 KiB per m-tile
+    auto go = [&](auto mt_c) {
+        constexpr int MTc = decltype(mt_c)::value;
+        static bool attr = false;                                 // (one flag per instantiation)
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr = true;
+        }
+        static const int probe = getenv("SD_ROWS_PROBE") ? atoi(getenv("SD_ROWS_PROBE")) : 0;
+        hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
+                           (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, e, probe);
+    };
+    if (MT == 2) go(std::integral_constant<int, 2>{});
+    else if (MT == 3) go(std::integral_constant<int, 3>{});
+    else if (MT == 4) go(std::integral_constant<int, 4>{});
+    else { sd_set_error("gemm_rows: %d rows", M); return SD_ERR_INVALID; }
+    return SD_OK;
+}
+
 static size_t gemm_part_floats(const sd_model_config &c, int N, int K, int rows) {
     if (!is16(c.dtype)) return (size_t)rows * N;
     size_t best = 0;
     for (int m = 1; m <= rows; m = (m % 16 == 0 ? m + 1 : (int)align_up(m, 16))) {       // every plan class: 1, 16, 17, 32, 33, ...
         const GemmPlan pl = gemm_plan(N, K, m);
         best = std::max(best, (size_t)pl.S * align_up(m, 16) * N);
+        const RowsPlan rp = rows_plan(N, K, m, false);
+        if (rp.ok) best = std::max(best, (size_t)rp.S * align_up(m, 16) * N);
     }
     return best;
 }
@@ -731,8 +793,21 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
         const int S = pl.S, ksp = pl.ksp;
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
+        bool xmap_identity = true;                                // (the balanced kernel reads whole activation tiles)
+        if (xtab)
+            for (int i = 0; i < M && xmap_identity; ++i) xmap_identity = xtab->xmap[i] == i;
+        const RowsPlan rp = xmap_identity ? rows_plan(N, K, M, false) : RowsPlan{};
         if (pl.tiled) {
             launch_gemm_tiled<H>(W, X, s->part, M, Mpad, N, K, pl, st);
+        } else if (rp.ok) {
+            SD_REQUIRE((size_t)rp.S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
+            GemmEpiT<H> e = {};
+            const int rc = launch_gemm_rows<EPI_PART, H>(W, X, s->part, M, Mpad, N, K, rp, e, st);
+            if (rc != SD_OK) return rc;
+            go->S = rp.S;
+            go->stride_s = (size_t)Mpad * N;
+            SD_LAUNCH_CHECK();
+            return SD_OK;
         } else {
             GemmEpiT<H> e = {};
             if (xtab) { e.use_xmap = 1; e.tab = *xtab; }
@@ -758,7 +833,9 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
                           hipStream_t st) {
     ProfScope ps(s, PC_GEMM, st);
     const int Mpad = (int)align_up(M, 16);
-    const int rc = dispatch_gemm_bf16<EPI, H>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);
+    const RowsPlan rp = (e.use_xmap || e.x_rowmajor) ? RowsPlan{} : rows_plan(N, K, M, true);
+    const int rc = rp.ok ? launch_gemm_rows<EPI, H>(W, X, nullptr, M, Mpad, N, K, rp, e, st)
+                         : dispatch_gemm_bf16<EPI, H>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);
     if (rc != SD_OK) return rc;
     SD_LAUNCH_CHECK();
     return SD_OK;
@@ -1543,6 +1620,23 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, in
         return SD_OK;
     }
     SD_REQUIRE(M <= 64, "sd_gemm_bf16: more than 64 rows need the tile layout (x_tiled) and N %% 128 == 0");
+    if (x_tiled) {
+        const RowsPlan rp = rows_plan(N, K, M, false);
+        if (rp.ok) {
+            SD_REQUIRE((size_t)rp.S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)rp.S * Mpad * N);
+            GemmEpi e0 = {};
+            if (launch_gemm_rows<EPI_PART, bf16_t>(w_packed, x, part, M, Mpad, N, K, rp, e0, (hipStream_t)stream) != SD_OK)
+                return SD_ERR_INVALID;
+            SD_LAUNCH_CHECK();
+            if (out) {
+                hipLaunchKernelGGL(reduce_f32_kernel, dim3((M * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, rp.S,
+                                   (size_t)Mpad * N, M * N, out);
+                SD_LAUNCH_CHECK();
+            }
+            if (splits_out) *splits_out = rp.S;
+            return SD_OK;
+        }
+    }
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
     GemmEpi e = {};

@@ -772,18 +772,38 @@ def g10_filter_lowprec():
                 finally:
                     SR.STABLE_TIES = False
                 kept = np.nonzero(torch.isfinite(out[0]).numpy())[0].astype(np.int32)
+                # Does the kept set hinge on the ORDER in which torch's vectorised CPU softmax sums its fp32 denominator
+                # over the row?  Redo the filter with an exactly rounded softmax (float64, then the row dtype): if that
+                # moves the cut, no other implementation can be expected to reproduce torch's last bit there.
+                alt = None
+                if p > 0:
+                    zz = x.clone()
+                    if k > 0:
+                        zz[zz < torch.topk(zz, min(k, V))[0][..., -1, None]] = float("-inf")
+                    srt, order = torch.sort(zz, descending=True)
+                    cs = torch.cumsum(torch.softmax(srt.double(), dim=-1).to(dtype), dim=-1)
+                    rem = cs > p
+                    rem[..., 1:] = rem[..., :-1].clone()
+                    rem[..., 0] = False
+                    zz[0, order[rem]] = float("-inf")
+                    alt = np.nonzero(torch.isfinite(zz[0]).numpy())[0].astype(np.int32)
+                    if alt.size == kept.size and (alt == kept).all():
+                        alt = None
                 # the fp32 run of the same (16-bit-valued) row: where it keeps a different set the dtype mode matters
                 k32 = np.nonzero(torch.isfinite(ref_utils.top_k_top_p_filter(x.float().clone(), top_k=k, top_p=p)[0]).numpy())[0]
                 key = f"f{cid}"
                 blobs[key + "_kept"] = kept
+                if alt is not None:
+                    blobs[key + "_kept_exact_softmax"] = alt
                 cases.append(dict(id=key, seed=seed, V=V, scale=4.0, k=k, p=p, dtype=str(dtype).split(".")[1],
-                                  n_kept=int(kept.size), differs_from_fp32=bool(k32.size != kept.size or (k32 != kept).any()),
+                                  n_kept=int(kept.size), sum_order_sensitive=alt is not None, differs_from_fp32=bool(k32.size != kept.size or (k32 != kept).any()),
                                   tie_sensitive=not torch.equal(st, out)))
                 cid += 1
     np.savez_compressed(os.path.join(HERE, "g10_filter_lowprec.npz"), **blobs)
     json.dump(cases, open(os.path.join(HERE, "g10_filter_lowprec.json"), "w"), indent=0)
     print("G10:", len(cases), "rows; kept set differs from the fp32 run in", sum(c["differs_from_fp32"] for c in cases),
-          "; tie-sensitive", sum(c["tie_sensitive"] for c in cases))
+          "; tie-sensitive", sum(c["tie_sensitive"] for c in cases), "; softmax-sum-order sensitive",
+          [c["id"] for c in cases if c["sum_order_sensitive"]])
 
 
 def misc():

@@ -1129,8 +1129,15 @@ def test_lowprec_top_k_top_p_filter_golden(hip, case):
     want = G10[case["id"] + "_kept"]
     z = x.float().numpy()[0]
     np.testing.assert_array_equal(g[kept], z[kept])              # kept logits are untouched
-    if not case["tie_sensitive"]:
-        np.testing.assert_array_equal(kept, want)
-    else:
-        assert len(kept) == len(want)
-        np.testing.assert_array_equal(np.sort(z[kept]), np.sort(z[want]))     # same logit multiset: twins at the cut
+    wants = [want]
+    if case.get("sum_order_sensitive"):
+        # the cut of this row hinges on the last bit of torch's fp32 softmax denominator, i.e. on the order in which its
+        # vectorised CPU kernel adds 50272 terms (make_golden.py: an exactly rounded softmax moves the cut by one token):
+        # either of the two recorded sets is a faithful answer
+        wants.append(G10[case["id"] + "_kept_exact_softmax"])
+
+    def same(w):
+        if not case["tie_sensitive"]:
+            return np.array_equal(kept, w)
+        return len(kept) == len(w) and np.array_equal(np.sort(z[kept]), np.sort(z[w]))   # same logit multiset: twins at the cut
+    assert any(same(w) for w in wants), (len(kept), [len(w) for w in wants])

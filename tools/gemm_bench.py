@@ -64,9 +64,10 @@ if __name__ == "__main__":
             for n in ("qkv", "o", "gate_up", "down"):
                 bench(n, *SHAPES[n], M=M)
     if sys.argv[1:] == ["rows"]:
-        for ntw in ("4", "8"):
-            os.environ["SD_GEMM_NTW"] = ntw
-            for n in ("qkv", "o", "gate_up", "down"):
-                for M in (40, 64):
-                    print("NTW", ntw, end=" ")
+        # 17..64 rows (stream-batched verify): the balanced one-workgroup-per-CU kernel against the streaming kernel
+        for rows_kernel in ("1", "0"):
+            os.environ["SD_GEMM_ROWS"] = rows_kernel
+            for n in ("qkv", "o", "gate_up", "down", "lm_head"):
+                for M in (20, 40, 60, 64):
+                    print("balanced" if rows_kernel == "1" else "stream  ", end=" ")
                     bench(n, *SHAPES[n], M=M)
