@@ -267,7 +267,7 @@ static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, 
 
 // ---- 17..64 rows: the balanced one-workgroup-per-CU kernel (rows_kernels.h).  S k-slabs x NG n-groups = one workgroup per
 // CU; a fused epilogue needs S == 1.  The plan minimises (weight bytes + slab traffic) / how evenly the n-tiles divide.
-struct RowsPlan { bool ok; int S, ksp, NG, grid; };
+struct RowsPlan { bool ok; int S, ksp, NG, grid, nwn, nwk, nld; };
 static RowsPlan rows_plan(int N, int K, int M, bool fused) {
     RowsPlan p = {};
     if (!g_env.gemm_rows || M <= 16 || M > 64 || N % 16 || K % 32) return p;
@@ -287,7 +287,14 @@ static RowsPlan rows_plan(int N, int K, int M, bool fused) {
             p.ok = eff >= 0.8;
         }
     }
-    if (p.ok) { p.S = (KS + p.ksp - 1) / p.ksp; p.grid = p.NG * p.S; }
+    if (p.ok) {
+        p.S = (KS + p.ksp - 1) / p.ksp;
+        p.grid = p.NG * p.S;
+        // wave grid of a workgroup: nwn compute waves per k-group (one n-tile each) x nwk k-groups + loader waves, <= 16
+        p.nwn = (NT + p.NG - 1) / p.NG;
+        p.nwk = std::min(4, (16 - 1) / p.nwn);
+        p.nld = std::min(p.nwk, 16 - p.nwn * p.nwk);
+    }
     return p;
 }
 
@@ -295,18 +302,19 @@ template <int EPI, typename H>
 static int launch_gemm_rows(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, const RowsPlan &pl,
                             const GemmEpiT<H> &e, hipStream_t st) {
     const int MT = Mpad / 16;
-    const size_t lds = (size_t)16 * 1024 * MT;                    // activation ring == fold buffer: 16 KiB per m-tile
+    // activation panel (2 buffers x nwk k-groups x GR_CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x 4 x MT)
+    const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * GR_CH, 4 * pl.nwn);
     auto go = [&](auto mt_c) {
         constexpr int MTc = decltype(mt_c)::value;
         static bool attr = false;                                 // (one flag per instantiation)
         if (!attr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr = true;
         }
         static const int probe = getenv("SD_ROWS_PROBE") ? atoi(getenv("SD_ROWS_PROBE")) : 0;
         hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
-                           (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, e, probe);
+                           (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e, probe);
     };
     if (MT == 2) go(std::integral_constant<int, 2>{});
     else if (MT == 3) go(std::integral_constant<int, 3>{});

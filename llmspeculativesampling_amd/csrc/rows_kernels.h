@@ -10,135 +10,156 @@
 //   * n-tiles are dealt to the NG = grid / SB n-groups as evenly as integers allow (ranges differ by at most one tile:
 //     Llama-2-13b QKV 960 tiles -> 3 or 4 per CU, gate/up 1728 -> 6 or 7), so SB = 1 fills 256 CUs to 94-98 % and the
 //     QKV / SiLU epilogues stay fused; O / down (320 tiles) take SB = 4 (5 tiles x a quarter of K per CU, exact);
-//   * inside a workgroup wave (kq, nw) = (k-quarter, n-wave) owns tiles t0 + nw and t0 + nw + 4 over a quarter of the
-//     workgroup's k-range - the streaming kernel's quarters and k order, so a dot product is accumulated in the same
-//     order and the fold through LDS gives the same bits;
-//   * the activation chunk of a k-quarter (GR_CH k-steps x MT tiles, already in MFMA fragment order) is fetched ONCE by
-//     the quarter's four n-waves and shared through LDS: X traffic per CU is MT KiB per k-step instead of MT per wave;
-//   * weights go straight to registers (non-temporal, read once), two chunks ahead of the MFMAs that use them.
-// One workgroup barrier per chunk (every ~2.6 us of weight stream per CU).
+//   * COMPUTE wave (ni, kg) owns ONE n-tile (t0 + ni) over one of the nwk k-groups of the workgroup's k-range; its
+//     weights go straight to registers (non-temporal, read once) through a 4-slot ring: three chunks of GR_CH k-steps
+//     (12 KiB per wave) are in flight while the fourth is multiplied, and nothing but weight loads sits in its VMEM queue;
+//   * LOADER waves (one per k-group while waves are left, else shared) move the k-group's activation chunk - GR_CH k-steps
+//     x MT tiles, already in MFMA fragment order - from L2 into a double-buffered LDS panel by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers), one chunk ahead; every compute wave of the k-group reads its
+//     fragments from there, so X traffic per CU is MT KiB per k-step however many tiles the CU owns;
+//   * one workgroup barrier per chunk hands the panel over (loader: its DMA has landed; compute waves: the previous
+//     panel is no longer read).
+// After the k-loop the nwk partial accumulators of every tile are folded through LDS and thread group tid / 256 runs the
+// tile's epilogue with the streaming kernel's code (gemm_epilogue_step).
 #pragma once
 #include "model_kernels.h"
 
-#define GR_CH 2                                               // k-steps per chunk
-#define GR_RW 3                                               // register slots of the weight ring (2 chunks in flight)
-#define GR_MAX_TILES 8                                        // n-tiles per workgroup (2 per n-wave)
+#define GR_CH 4                                               // k-steps per chunk (one barrier per chunk)
+#define GR_RW 4                                               // register slots of the weight ring (3 chunks in flight)
+#define GR_MAX_TILES 7                                        // n-tiles per workgroup = compute waves per k-group
 #define GR_THREADS 1024
+
+// one 1 KiB tile L2 -> LDS: lane l's 16 bytes at gsrc go to lds_dst + 16 l (M0 carries the wave-uniform LDS address).
+// Default cache policy: the activation panel is re-read by every CU.
+__device__ __forceinline__ void gr_glds16(const u32x4 *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 template <int MT, int EPI, typename H = bf16_t>
 __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
                                                             float *__restrict__ part, int M, int Mpad, int N, int K,
-                                                            int NG, int ks_per_blk, GemmEpiT<H> e, int probe = 0) {
+                                                            int NG, int ks_per_blk, int nwn, int nwk, int nld,
+                                                            GemmEpiT<H> e, int probe = 0) {
     // probe (SD_ROWS_PROBE, timing experiments only - results are wrong): 1 no activation loads, 2 no barriers, 4 no MFMAs
-    constexpr int NXT = MT * GR_CH;                               // activation tiles per chunk and k-quarter
-    constexpr int XW = (NXT + 3) / 4;                             // of which one n-wave fetches at most XW
     extern __shared__ __attribute__((aligned(16))) char gr_smem[];
-    // activation ring [2][kq][ck][mt][lane]; after the k-loop the same bytes hold the fold buffer [tile 0..3][kq][mt][lane]
-    u32x4 (*xs)[4][GR_CH][MT][64] = reinterpret_cast<u32x4 (*)[4][GR_CH][MT][64]>(gr_smem);
+    // activation panel [2][kg][ck][mt][lane]; after the k-loop the same bytes hold the fold buffer [tile][4][mt][lane]
+    u32x4 (*xs)[GR_CH][MT][64] = reinterpret_cast<u32x4 (*)[GR_CH][MT][64]>(gr_smem);      // xs[buf * nwk + kg]
     f32x4 (*red)[4][MT][64] = reinterpret_cast<f32x4 (*)[4][MT][64]>(gr_smem);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kq = wv >> 2, nw = wv & 3;
     const int NT = N >> 4, KS = K >> 5;
     const int g = blockIdx.x % NG, sb = blockIdx.x / NG;
     const int t0 = (int)((long long)g * NT / NG), t1 = (int)((long long)(g + 1) * NT / NG);
     const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
-    const int per = (kb1 - kb0 + 3) >> 2;                         // gemm_bf16_stream's quarters
-    const int ks0 = min(kb1, kb0 + kq * per), ks1 = min(kb1, ks0 + per);
+    const int per = (kb1 - kb0 + nwk - 1) / nwk;                  // k-steps per k-group
     const int nch = (per + GR_CH - 1) / GR_CH;                    // chunks: the same count for every wave (barriers)
-    const bool has[2] = {t0 + nw < t1, t0 + nw + 4 < t1};
-    const u32x4 *wp[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) wp[j] = Wp + ((size_t)(has[j] ? t0 + nw + 4 * j : 0) * KS + ks0) * 64 + lane;
-    const u32x4 *xp = Xp + (size_t)ks0 * 64 + lane;              // tile (mt, ks0 + d) at xp + (mt * KS + d) * 64
+    const int ncomp = nwn * nwk;
+    auto bar = [&]() { if (!(probe & 2)) __syncthreads(); };
 
-    f32x4 acc[2][MT];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // every operand register is written on every path (a skipped load leaves zeros, never stale bits: DESIGN.md section 7)
-    u32x4 wr[GR_RW][2][GR_CH];
-    u32x4 xr[2][XW];
-    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ni = wv % nwn, kg = wv / nwn;                       // (meaningful for compute waves)
+    const bool comp = wv < ncomp && t0 + ni < t1;
 
-    auto issue_w = [&](auto slot_c, int c) {
-        constexpr int slot = decltype(slot_c)::value;
+    if (wv >= ncomp && wv < ncomp + nld) {
+        // ---------------- loader: k-groups ld, ld + nld, ... ----------------
+        const int ld = wv - ncomp;
+        auto dma = [&](int c, int buf) {
+            if (probe & 1) return;
+            for (int k2 = ld; k2 < nwk; k2 += nld) {
+                const int ks0 = min(kb1, kb0 + k2 * per), ks1 = min(kb1, ks0 + per);
+                const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)(unsigned)(uintptr_t)&xs[buf * nwk + k2][0][0][0]);               // LDS byte address (wave-uniform)
 #pragma unroll
-        for (int ck = 0; ck < GR_CH; ++ck) {
-            const int d = c * GR_CH + ck;
-            const bool ok = ks0 + d < ks1;
+                for (int ck = 0; ck < GR_CH; ++ck) {
+                    const int ks = ks0 + c * GR_CH + ck;
+                    if (ks < ks1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                wr[slot][j][ck] = (ok && has[j]) ? __builtin_nontemporal_load(wp[j] + (size_t)d * 64) : zero;
-        }
-    };
-    auto issue_x = [&](auto slot_c, int c) {
-        constexpr int slot = decltype(slot_c)::value;
-#pragma unroll
-        for (int j = 0; j < XW; ++j) {
-            const int i = nw + 4 * j, ck = i / MT, mt = i - ck * MT, d = c * GR_CH + ck;
-            const bool ok = i < NXT && ks0 + d < ks1 && mt * 16 < Mpad && !(probe & 1);
-            xr[slot][j] = ok ? xp[((size_t)mt * KS + d) * 64] : zero;
-        }
-    };
-    auto put_x = [&](auto slot_c, int buf) {
-        constexpr int slot = decltype(slot_c)::value;
-#pragma unroll
-        for (int j = 0; j < XW; ++j) {
-            const int i = nw + 4 * j, ck = i / MT, mt = i - ck * MT;
-            if (i < NXT) xs[buf][kq][ck][mt][lane] = xr[slot][j];
-        }
-    };
-    auto compute = [&](auto slot_c, int buf) {
-        constexpr int slot = decltype(slot_c)::value;
-#pragma unroll
-        for (int ck = 0; ck < GR_CH; ++ck) {
-            u32x4 xf[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) xf[t] = xs[buf][kq][ck][t][lane];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (has[j] && !(probe & 4)) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[j][t] = mfma16<H>(wr[slot][j][ck], xf[t], acc[j][t]);
-                } else if (probe & 4) {
-                    acc[j][0][0] += __uint_as_float(wr[slot][j][ck][0] & 1u);     // (keeps the loads alive)
+                        for (int t = 0; t < MT; ++t)
+                            gr_glds16(Xp + ((size_t)t * KS + ks) * 64 + lane, base + (unsigned)((ck * MT + t) * 1024));
+                    }
                 }
+            }
+        };
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int c = 0; c < nch; ++c) {
+            bar();                                                // compute(c - 1) is over: panel (c + 1) & 1 is free
+            if (c + 1 < nch) {
+                dma(c + 1, (c + 1) & 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // landed before this wave arrives at the next barrier
+            }
         }
-    };
-    using std::integral_constant;
-    issue_w(integral_constant<int, 0>{}, 0);
-    issue_x(integral_constant<int, 0>{}, 0);
-    issue_w(integral_constant<int, 1>{}, 1);
-    issue_x(integral_constant<int, 1>{}, 1);
-    put_x(integral_constant<int, 0>{}, 0);
-    // step I of six (lcm of the 3 weight slots and the 2 activation slots / buffers): chunk c = base + I
-    auto step = [&](auto I_c, int c) {
-        constexpr int I = decltype(I_c)::value;
-        if (!(probe & 2)) __syncthreads();                        // chunk c's activations are in LDS; nobody reads c - 1 any more
-        issue_w(integral_constant<int, (I + 2) % GR_RW>{}, c + 2);
-        issue_x(integral_constant<int, I % 2>{}, c + 2);          // (chunk c's staging registers were stored a step ago)
-        compute(integral_constant<int, I % GR_RW>{}, I % 2);
-        put_x(integral_constant<int, (I + 1) % 2>{}, (I + 1) % 2);   // chunk c + 1 -> the buffer chunk c - 1 used
-    };
-    for (int base = 0; base < nch; base += 6) {
-        step(integral_constant<int, 0>{}, base);
-        if (base + 1 < nch) step(integral_constant<int, 1>{}, base + 1);
-        if (base + 2 < nch) step(integral_constant<int, 2>{}, base + 2);
-        if (base + 3 < nch) step(integral_constant<int, 3>{}, base + 3);
-        if (base + 4 < nch) step(integral_constant<int, 4>{}, base + 4);
-        if (base + 5 < nch) step(integral_constant<int, 5>{}, base + 5);
+    } else if (comp) {
+        // ---------------- compute: tile t0 + ni, k-group kg ----------------
+        const int ks0 = min(kb1, kb0 + kg * per), ks1 = min(kb1, ks0 + per);
+        const u32x4 *wp = Wp + ((size_t)(t0 + ni) * KS + ks0) * 64 + lane;
+        // every operand register is written on every path (a skipped load leaves zeros, never stale bits: DESIGN.md 7)
+        u32x4 wr[GR_RW][GR_CH];
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        auto issue_w = [&](auto slot_c, int c) {
+            constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+            for (int ck = 0; ck < GR_CH; ++ck) {
+                const int d = c * GR_CH + ck;
+                wr[slot][ck] = ks0 + d < ks1 ? __builtin_nontemporal_load(wp + (size_t)d * 64) : zero;
+            }
+        };
+        auto compute = [&](auto slot_c, int c) {
+            constexpr int slot = decltype(slot_c)::value;
+            const int pbuf = (c & 1) * nwk + kg;
+#pragma unroll
+            for (int ck = 0; ck < GR_CH; ++ck) {
+                if (ks0 + c * GR_CH + ck < ks1) {                 // (a k-step past the range: its panel tile was never written)
+                    u32x4 xf[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) xf[t] = (probe & 1) ? zero : xs[pbuf][ck][t][lane];
+                    if (!(probe & 4)) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[t] = mfma16<H>(wr[slot][ck], xf[t], acc[t]);
+                    } else {
+                        acc[0][0] += __uint_as_float((wr[slot][ck][0] ^ xf[0][0]) & 1u);       // (keeps the loads alive)
+                    }
+                }
+            }
+        };
+        using std::integral_constant;
+        issue_w(integral_constant<int, 0>{}, 0);
+        issue_w(integral_constant<int, 1>{}, 1);
+        issue_w(integral_constant<int, 2>{}, 2);
+        auto step = [&](auto I_c, int c) {
+            constexpr int I = decltype(I_c)::value;
+            bar();                                                // chunk c's panel is in LDS
+            issue_w(integral_constant<int, (I + 3) % GR_RW>{}, c + 3);
+            compute(integral_constant<int, I>{}, c);
+        };
+        for (int base = 0; base < nch; base += GR_RW) {
+            step(integral_constant<int, 0>{}, base);
+            if (base + 1 < nch) step(integral_constant<int, 1>{}, base + 1);
+            if (base + 2 < nch) step(integral_constant<int, 2>{}, base + 2);
+            if (base + 3 < nch) step(integral_constant<int, 3>{}, base + 3);
+        }
+    } else {
+        for (int c = 0; c < nch; ++c) bar();                      // idle wave: keeps the barrier count
     }
-    // Fold the four k-quarters through LDS, the tiles of one n-wave slot (j) at a time; thread group g4 = tid / 256 then
-    // runs the epilogue of tile t0 + g4 + 4 j exactly as a streaming-kernel workgroup would (same fold order, same code).
+    // ---- fold the k-groups' accumulators through LDS (slots past nwk hold zeros), then the epilogue: thread group
+    // tid / 256 takes tile t0 + tid / 256 (+ 4 in the second round) exactly as a streaming-kernel workgroup would
+    __syncthreads();
+    if (comp) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            red[ni][kg][t][lane] = acc[t];
+            if (kg == 0)
+                for (int z = nwk; z < 4; ++z) red[ni][z][t][lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < MT; ++t) red[nw][kq][t][lane] = acc[j][t];               // red[tile nw][kq][mt][lane]
-        __syncthreads();
-        const int g4 = threadIdx.x >> 8, tile = t0 + g4 + 4 * j;
-        if (tile < t1)
+        const int g4 = (int)(threadIdx.x >> 8) + 4 * j, tile = t0 + g4;
+        if (g4 < nwn && tile < t1)
             gemm_epilogue_step<MT, EPI, 1, MT, H>(red[g4], 0, part, M, Mpad, N, sb, tile, e, (int)(threadIdx.x & 255));
     }
 }

@@ -591,8 +591,9 @@ def test_gemm_bf16_stream_vs_fp32_reference(hip, N, K):
                                          out2.data_ptr(), C.byref(S), _st()))
         err2 = float((out2 - ref).abs().max())
         assert err2 <= 2e-4 * float(ref.abs().max()) + 1e-5, (M, N, K, S.value, err2)
-        if M <= 32:
+        if M <= 16:
             assert torch.equal(out2, out), (M, N, K)                   # same kernel, same summation order
+        # (17..64 rows in the tile layout take the balanced one-workgroup-per-CU kernel, rows_kernels.h: another k-split)
 
 
 def test_norm_sample_fused_matches_two_step(hip):
