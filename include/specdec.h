@@ -341,6 +341,10 @@ typedef struct {
     int32_t pos0, n_new, n_logits;
 } sd_batch_item;
 int sd_batch_forward(const sd_batch_item *items, int n_items, float *logits_out, long ld_logits, void *stream);
+/* Batched prefill: the items' rows (each stream's n_new rows at positions pos0.. , a contiguous run; n_logits must be 0) go
+ * through ONE pass over the weights - up to 256 rows and 32 attention groups (8 consecutive rows of one stream) in all.
+ * K / V rows are appended to every stream's own arena; nothing else comes back.  All sessions share one model. */
+int sd_batch_prefill(const sd_batch_item *items, int n_items, void *stream);
 
 /* One whole speculative iteration enqueued natively (device-RNG mode), reference speculative_sampling.py:1934-2031:
  * gamma x (draft forward over the uncached rows + sd_norm_sample straight into seq[]), one target forward over its

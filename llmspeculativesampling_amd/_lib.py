@@ -121,6 +121,7 @@ SYMBOLS = [
     ("sd_spec_generate", _I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, C.c_uint64, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP, _VP]),
     ("sd_batch_forward", _I, [C.POINTER(SdBatchItem), _I, _VP, _L, _VP]),
+    ("sd_batch_prefill", _I, [C.POINTER(SdBatchItem), _I, _VP]),
     ("sd_spec_create", _I, [_VP, _VP, _I, _F, _I, _F, _VP, _VP, _VP, _L, _VP, _L, _VP, _L, _VP, _VP, _VP, C.POINTER(_VP)]),
     ("sd_spec_destroy", _I, [_VP]),
     ("sd_spec_iteration", _I, [_VP, _I, _I, _I, _U64, _U64, _U64, _U64, _U64, _VP, _VP, _VP, _VP]),

@@ -1379,6 +1379,17 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
 // fill the attention groups and the lm_head row map of a table whose rows are already laid out stream by stream
 static void finish_table(RowTab &tab) {
     tab.n_groups = 0;
+    if (tab.contig == 2) {                          // runs of several streams: groups of ATT_TQ consecutive rows inside a run
+        for (int i = 0; i < tab.n_streams; ++i)
+            for (int r = tab.seg_row0[i]; r < tab.seg_row0[i + 1]; r += ATT_TQ) {
+                const int g = tab.n_groups++;
+                tab.grp_row0[g] = r;
+                tab.grp_n[g] = std::min(ATT_TQ, tab.seg_row0[i + 1] - r);
+                tab.grp_pos[g] = tab.seg_pos0[i] + (r - tab.seg_row0[i]);
+                tab.grp_stream[g] = i;
+            }
+        return;
+    }
     if (tab.contig) {                               // up to 256 rows = 32 groups of ATT_TQ consecutive positions
         for (int r = 0; r < tab.n_rows; r += ATT_TQ) {
             const int g = tab.n_groups++;
@@ -1588,6 +1599,48 @@ extern "C" int sd_batch_forward(const sd_batch_item *items, int n_items, float *
     tab.n_logit_rows = nlog;
     finish_table(tab);
     return run_forward(s0, tab, s_max, logits_out, ld_logits, stream);
+}
+
+// Batched prefill (throughput mode): the prompts of several streams through ONE pass over the weights - up to
+// SD_MAX_FWD_ROWS rows and SD_MAX_GROUPS attention groups in all, every stream's rows a contiguous run of positions
+// (RowTab contig = 2), no logits.  Replaces stream-by-stream prefill passes of the same weights.
+extern "C" int sd_batch_prefill(const sd_batch_item *items, int n_items, void *stream) {
+    SD_REQUIRE(items && n_items >= 1 && n_items <= SD_MAX_STREAMS, "sd_batch_prefill: 1..%d items", SD_MAX_STREAMS);
+    sd_session *s0 = items[0].session;
+    SD_REQUIRE(s0, "sd_batch_prefill: null session");
+    RowTab tab = {};
+    int rows = 0, groups = 0, s_max = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const sd_batch_item &it = items[i];
+        SD_REQUIRE(it.session && it.seq && it.session->m == s0->m, "sd_batch_prefill: item %d: null or foreign session", i);
+        SD_REQUIRE(it.n_new >= 1 && it.pos0 >= 0 && it.n_logits == 0, "sd_batch_prefill: item %d: n_new=%d pos0=%d n_logits=%d",
+                   i, it.n_new, it.pos0, it.n_logits);
+        SD_REQUIRE(it.session->kv_fp8 == s0->kv_fp8, "sd_batch_prefill: item %d: KV arenas of different dtypes", i);
+        groups += (it.n_new + ATT_TQ - 1) / ATT_TQ;
+        if (it.pos0 + it.n_new > it.session->max_seq || rows + it.n_new > std::min(s0->max_rows, SD_MAX_FWD_ROWS) ||
+            groups > SD_MAX_GROUPS) {
+            sd_set_error("sd_batch_prefill: item %d overflows (rows %d+%d of %d, %d attention groups of %d, positions %d of %d)", i,
+                         rows, it.n_new, std::min(s0->max_rows, SD_MAX_FWD_ROWS), groups, SD_MAX_GROUPS, it.pos0 + it.n_new,
+                         it.session->max_seq);
+            return SD_ERR_CAPACITY;
+        }
+        tab.tok_base[i] = it.seq;
+        tab.kv_base[i] = it.session->kv;
+        tab.max_seq[i] = it.session->max_seq;
+        tab.kv_fp8 = it.session->kv_fp8;
+        tab.kv_scale[i] = it.session->kv_scale;
+        tab.seg_row0[i] = rows;
+        tab.seg_pos0[i] = it.pos0;
+        rows += it.n_new;
+        s_max = std::max(s_max, it.pos0 + it.n_new);
+    }
+    tab.seg_row0[n_items] = rows;
+    tab.contig = 2;
+    tab.n_rows = rows;
+    tab.n_streams = n_items;
+    tab.n_logit_rows = 0;
+    finish_table(tab);
+    return run_forward(s0, tab, s_max, nullptr, 0, stream);
 }
 
 // ---- standalone weight-streaming GEMM (unit tests + kernel-level roofline runs) --------------

@@ -29,9 +29,12 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 #define SD_MAX_GROUPS 32
 struct RowTab {
     int n_rows, n_streams, n_groups, n_logit_rows;
-    int contig, pos0;                               // contig: one stream, row m at position pos0 + m (the only form with
-                                                    // more than SD_MAX_ROWS rows: prefill chunks of up to 256); the two
-                                                    // per-row arrays below are then unused
+    int contig, pos0;                               // contig 1: one stream, row m at position pos0 + m (prefill chunks of
+                                                    // up to 256 rows); contig 2: n_streams such runs back to back - rows
+                                                    // seg_row0[i] .. seg_row0[i+1]-1 are stream i at seg_pos0[i] + (m -
+                                                    // seg_row0[i]) (batched prefill of several prompts in one pass).  The
+                                                    // two per-row arrays below are unused in both forms
+    int seg_row0[SD_MAX_STREAMS + 1], seg_pos0[SD_MAX_STREAMS];
     int row_pos[SD_MAX_ROWS];                       // absolute position of row m in its sequence
     unsigned char row_stream[SD_MAX_ROWS];          // stream of row m
     unsigned char xmap[SD_MAX_ROWS];                // rows of the hidden state that feed the lm_head, in output order
@@ -63,8 +66,18 @@ __device__ __forceinline__ size_t xoff(int m, int k, int K) {
         return (size_t)m * K + k;
 }
 
-__device__ __forceinline__ int tab_pos(const RowTab &t, int m) { return t.contig ? t.pos0 + m : t.row_pos[m]; }
-__device__ __forceinline__ int tab_stream(const RowTab &t, int m) { return t.contig ? 0 : (int)t.row_stream[m]; }
+__device__ __forceinline__ int tab_stream(const RowTab &t, int m) {
+    if (t.contig == 2) {                            // <= 16 runs: the last one that starts at or before row m
+        int sg = 0;
+        for (int i = 1; i < t.n_streams; ++i) sg += (t.seg_row0[i] <= m);
+        return sg;
+    }
+    return t.contig ? 0 : (int)t.row_stream[m];
+}
+__device__ __forceinline__ int tab_pos(const RowTab &t, int m) {
+    if (t.contig == 2) { const int sg = tab_stream(t, m); return t.seg_pos0[sg] + (m - t.seg_row0[sg]); }
+    return t.contig ? t.pos0 + m : t.row_pos[m];
+}
 // token id of row m: read at its absolute position in the stream's token buffer, or (tree verify) at its node index
 __device__ __forceinline__ int tab_tok(const RowTab &t, int m, int pos) {
     return t.tree ? t.tok_base[0][m] : t.tok_base[tab_stream(t, m)][pos];

@@ -458,3 +458,46 @@ def batch_forward(sessions: List[Session], seqs: List[torch.Tensor], n_new: List
     for ses, n in zip(sessions, n_new):
         ses.cache_len += int(n)
     return logits_out[:tot]
+
+
+def batch_prefill(sessions: List[Session], seqs: List[torch.Tensor], n_new: List[int]) -> None:
+    """Batched prefill (sd_batch_prefill): stream i feeds seqs[i][cache_len : cache_len + n_new[i]] with no logits.  The
+    streams are packed greedily into passes of at most MAX_PREFILL_ROWS rows / 32 attention groups / 16 streams, so B
+    prompts cost ceil(rows / 256) passes over the weights instead of B; a stream whose run does not fit one pass is fed
+    by its own chunked Session.forward.  All sessions share one model."""
+    st = _stream()
+    chunk: List[int] = []
+    rows = groups = 0
+
+    def flush():
+        nonlocal chunk, rows, groups
+        if not chunk:
+            return
+        items = (_lib.SdBatchItem * len(chunk))()
+        for j, i in enumerate(chunk):
+            items[j].session = sessions[i].handle
+            items[j].seq = seqs[i].data_ptr()
+            items[j].pos0 = sessions[i].cache_len
+            items[j].n_new = int(n_new[i])
+            items[j].n_logits = 0
+        check(lib.sd_batch_prefill(items, len(chunk), st), "sd_batch_prefill")
+        for i in chunk:
+            sessions[i].cache_len += int(n_new[i])
+        chunk, rows, groups = [], 0, 0
+
+    cap = min([MAX_PREFILL_ROWS] + [s.max_rows for s in sessions])
+    for i, (ses, n) in enumerate(zip(sessions, n_new)):
+        n = int(n)
+        if n <= 0:
+            continue
+        g = (n + 7) // 8
+        if n > cap or g > 32:
+            flush()
+            ses.forward(seqs[i][ses.cache_len:ses.cache_len + n], 0)
+            continue
+        if rows + n > cap or groups + g > 32 or len(chunk) >= 16:
+            flush()
+        chunk.append(i)
+        rows += n
+        groups += g
+    flush()

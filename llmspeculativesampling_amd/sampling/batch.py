@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .._lib import lib, check, SdAcceptResult, SdBatchStream
-from ..engine import as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device
+from ..engine import as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, check_token_ids, same_device, batch_prefill
 from ..noise import DeviceNoise
 from .kvcache_model import KVCacheModel
 
@@ -75,15 +75,17 @@ def speculative_sampling_batch(prefixes: Sequence[torch.Tensor], approx_model, t
         st.out = st.host
         st.acc_len, st.acc_rate, st.calls = [], [], 0
         st.err = torch.zeros(n_err, dtype=torch.int32, device=dev)
-        # prefill everything but the last prompt token stream by stream (rows beyond one pass's budget anyway);
-        # the decode loop then starts with 1 new draft row and gamma+1 new target rows like every later iteration
-        if L > 1:
-            st.draft._session.forward(st.seq32[:L - 1], 0)
-            st.target._session.forward(st.seq32[:L - 1], 0)
         st.draft_len = st.target_len = L - 1
         st.q_ptr, st.p_ptr = st.draft._probs.data_ptr(), st.target._probs.data_ptr()
         st.seq_ptr, st.err_ptr = st.seq32.data_ptr(), st.err.data_ptr()
         streams.append(st)
+
+    # prefill everything but the last prompt token, the B prompts packed into passes of up to 256 rows (engine.batch_prefill:
+    # one pass over the weights serves several streams); the decode loop then starts with 1 new draft row and gamma+1 new
+    # target rows per stream like every later iteration
+    for side in ("draft", "target"):
+        batch_prefill([getattr(s, side)._session for s in streams], [s.seq32 for s in streams],
+                      [s.prompt_len - 1 for s in streams])
 
     # the lock-step loop itself runs inside libspecdec (sd_spec_batch_generate): per iteration gamma batched draft steps,
     # the verify passes, the batched accept + residual sample, one copy of the result blocks and one wait - the

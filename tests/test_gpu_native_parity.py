@@ -941,3 +941,39 @@ def test_model_from_local_checkpoint_directory(hip, tmp_path):
     with torch.no_grad():
         want = llama(ids[None].long().cpu()).logits[0].float()
     assert float((la.cpu() - want).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_batched_prefill_equals_per_stream_prefill(hip, dtype):
+    """engine.batch_prefill / sd_batch_prefill: the prompts of several streams in ONE pass over the
+    weights (row table of contiguous runs, up to 256 rows / 32 attention groups) against stream-by-stream
+    Session.forward: every stream's K / V rows and the logits of the step that follows.  fp32 is bit-identical (the GEMM
+    is row-independent); bf16 takes another k-slab plan at another row count, so it is held to the bf16 bar of the other
+    forward tests (0.25 on logits of scale ~10).  Five streams of 40 / 127 / 70 / 9 / 300 rows: two packed passes + one
+    stream that does not fit a pass and goes through its own chunked forward."""
+    cfg = ModelConfig(**BF16_CFG)
+    sd = make_state_dict(cfg, 5, dtype=dtype)
+    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
+    lens = [40, 127, 70, 9, 300]
+    rng = np.random.default_rng(17)
+    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(n + 1,))).to(torch.int32).cuda() for n in lens]
+    a = [m.new_session(320) for _ in lens]
+    b = [m.new_session(320) for _ in lens]
+    for ses, sq, n in zip(a, seqs, lens):
+        ses.forward(sq[:n], 0)
+    hip.engine.batch_prefill(b, seqs, lens)
+    tol = 0.0 if dtype == torch.float32 else 0.25
+    for sa, sb, sq, n in zip(a, b, seqs, lens):
+        assert sb.cache_len == n == sa.cache_len
+        ka, kb = sa.kv[:, :, :, :n].float(), sb.kv[:, :, :, :n].float()
+        assert float((ka - kb).abs().max()) <= tol * 0.1, (n, float((ka - kb).abs().max()))
+        la = sa.forward(sq[n:n + 1], 1).clone()
+        lb = sb.forward(sq[n:n + 1], 1).clone()
+        assert float((la - lb).abs().max()) <= tol, (n, float((la - lb).abs().max()))
+    # capacity errors: more than 256 rows / a logits request
+    items = (hip.L.SdBatchItem * 2)()
+    for j in range(2):
+        items[j].session, items[j].seq, items[j].pos0, items[j].n_new, items[j].n_logits = a[j].handle, seqs[j].data_ptr(), 0, 200, 0
+    assert hip.lib.sd_batch_prefill(items, 2, _st()) == hip.L.SD_ERR_CAPACITY
+    items[0].n_new, items[1].n_new, items[1].n_logits = 8, 8, 1
+    assert hip.lib.sd_batch_prefill(items, 2, _st()) == hip.L.SD_ERR_INVALID

@@ -383,6 +383,7 @@ def test_new_entry_points_reject_null_arguments_without_a_gpu():
     assert lib.sd_comm_all_gather_tokens(None, None, None, 1, 8, None) == _lib.SD_ERR_INVALID
     assert lib.sd_comm_rank(None, C.byref(z), C.byref(z)) == _lib.SD_ERR_INVALID
     assert lib.sd_comm_destroy(None) == _lib.SD_OK
+    assert lib.sd_batch_prefill(None, 0, None) == _lib.SD_ERR_INVALID and b"sd_batch_prefill" in lib.sd_last_error()
     buf = (C.c_float * 16)()
     assert lib.sd_topk_topp_filter(C.addressof(buf), 1, 16, 16, 4, 0.9, 7, C.addressof(buf), 16, None) == _lib.SD_ERR_INVALID
     assert b"dtype_mode" in lib.sd_last_error()
