@@ -312,9 +312,8 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             attr = true;
         }
-        static const int probe = getenv("SD_ROWS_PROBE") ? atoi(getenv("SD_ROWS_PROBE")) : 0;
         hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
-                           (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e, probe);
+                           (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e);
     };
     if (MT == 2) go(std::integral_constant<int, 2>{});
     else if (MT == 3) go(std::integral_constant<int, 3>{});

@@ -28,6 +28,9 @@
 #define GR_RW 4                                               // register slots of the weight ring (3 chunks in flight)
 #define GR_MAX_TILES 7                                        // n-tiles per workgroup = compute waves per k-group
 #define GR_THREADS 1024
+#ifndef GR_PROBE
+#define GR_PROBE 0
+#endif
 
 // one 1 KiB tile L2 -> LDS: lane l's 16 bytes at gsrc go to lds_dst + 16 l (M0 carries the wave-uniform LDS address).
 // Default cache policy: the activation panel is re-read by every CU.
@@ -41,8 +44,12 @@ template <int MT, int EPI, typename H = bf16_t>
 __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
                                                             float *__restrict__ part, int M, int Mpad, int N, int K,
                                                             int NG, int ks_per_blk, int nwn, int nwk, int nld,
-                                                            GemmEpiT<H> e, int probe = 0) {
-    // probe (SD_ROWS_PROBE, timing experiments only - results are wrong): 1 no activation loads, 2 no barriers, 4 no MFMAs
+                                                            GemmEpiT<H> e) {
+    // GR_PROBE (compile-time, timing experiments only - results are wrong): 1 no activation loads, 2 no barriers,
+    // 4 no MFMAs, 8 no weight loads, 16 no fold / epilogue.  Compile-time so that the production inner loop has no branch
+    // around a load: with one, hipcc's waitcnt insertion falls back to s_waitcnt vmcnt(0) at the loop's joins and the
+    // weight ring drains every chunk (seen in the ISA of the first cut of this kernel).
+    constexpr int probe = GR_PROBE;
     extern __shared__ __attribute__((aligned(16))) char gr_smem[];
     // activation panel [2][kg][ck][mt][lane]; after the k-loop the same bytes hold the fold buffer [tile][4][mt][lane]
     u32x4 (*xs)[GR_CH][MT][64] = reinterpret_cast<u32x4 (*)[GR_CH][MT][64]>(gr_smem);      // xs[buf * nwk + kg]
@@ -70,16 +77,16 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
             if (probe & 1) return;
             for (int k2 = ld; k2 < nwk; k2 += nld) {
                 const int ks0 = min(kb1, kb0 + k2 * per), ks1 = min(kb1, ks0 + per);
+                if (ks0 >= ks1) continue;                         // (an empty k-group: its compute waves multiply nothing)
                 const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)(unsigned)(uintptr_t)&xs[buf * nwk + k2][0][0][0]);               // LDS byte address (wave-uniform)
 #pragma unroll
                 for (int ck = 0; ck < GR_CH; ++ck) {
-                    const int ks = ks0 + c * GR_CH + ck;
-                    if (ks < ks1) {
+                    // a k-step past the range re-reads the last valid tile: finite values that meet a zero weight operand
+                    const int ks = min(ks0 + c * GR_CH + ck, ks1 - 1);
 #pragma unroll
-                        for (int t = 0; t < MT; ++t)
-                            gr_glds16(Xp + ((size_t)t * KS + ks) * 64 + lane, base + (unsigned)((ck * MT + t) * 1024));
-                    }
+                    for (int t = 0; t < MT; ++t)
+                        gr_glds16(Xp + ((size_t)t * KS + ks) * 64 + lane, base + (unsigned)((ck * MT + t) * 1024));
                 }
             }
         };
@@ -95,16 +102,24 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     } else if (comp) {
         // ---------------- compute: tile t0 + ni, k-group kg ----------------
         const int ks0 = min(kb1, kb0 + kg * per), ks1 = min(kb1, ks0 + per);
-        const u32x4 *wp = Wp + ((size_t)(t0 + ni) * KS + ks0) * 64 + lane;
-        // every operand register is written on every path (a skipped load leaves zeros, never stale bits: DESIGN.md 7)
+        const int nk = ks1 - ks0, dlast = max(nk - 1, 0);
+        const u32x4 *wp = Wp + ((size_t)(t0 + ni) * KS + min(ks0, KS - 1)) * 64 + lane;
+        // No branch around a load or an MFMA in this loop: a k-step past the wave's range re-loads the last valid tile
+        // and is multiplied as ZERO (selected at use, so the select does not wait for the load at issue time); the panel
+        // tile it meets holds finite values (the loader clamps the same way).  Every operand register is therefore
+        // written on every path.
         u32x4 wr[GR_RW][GR_CH];
         const u32x4 zero = {0u, 0u, 0u, 0u};
         auto issue_w = [&](auto slot_c, int c) {
             constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
             for (int ck = 0; ck < GR_CH; ++ck) {
-                const int d = c * GR_CH + ck;
-                wr[slot][ck] = ks0 + d < ks1 ? __builtin_nontemporal_load(wp + (size_t)d * 64) : zero;
+                const int d = min(c * GR_CH + ck, dlast);
+                wr[slot][ck] = (probe & 8) ? zero : __builtin_nontemporal_load(wp + (size_t)d * 64);
+                // keep the loads in program order: the VMEM queue returns in issue order, and hipcc otherwise permutes
+                // independent loads (the first cut's prologue issued chunk 0's tile eleventh of twelve, so its first
+                // wait was vmcnt(1): the whole ring drained)
+                asm volatile("" ::: "memory");
             }
         };
         auto compute = [&](auto slot_c, int c) {
@@ -112,16 +127,18 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
             const int pbuf = (c & 1) * nwk + kg;
 #pragma unroll
             for (int ck = 0; ck < GR_CH; ++ck) {
-                if (ks0 + c * GR_CH + ck < ks1) {                 // (a k-step past the range: its panel tile was never written)
-                    u32x4 xf[MT];
+                const bool valid = c * GR_CH + ck < nk;
+                u32x4 w = wr[slot][ck];
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) xf[t] = (probe & 1) ? zero : xs[pbuf][ck][t][lane];
-                    if (!(probe & 4)) {
+                for (int q = 0; q < 4; ++q) w[q] = valid ? w[q] : 0u;
+                u32x4 xf[MT];
 #pragma unroll
-                        for (int t = 0; t < MT; ++t) acc[t] = mfma16<H>(wr[slot][ck], xf[t], acc[t]);
-                    } else {
-                        acc[0][0] += __uint_as_float((wr[slot][ck][0] ^ xf[0][0]) & 1u);       // (keeps the loads alive)
-                    }
+                for (int t = 0; t < MT; ++t) xf[t] = (probe & 1) ? zero : xs[pbuf][ck][t][lane];
+                if (!(probe & 4)) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16<H>(w, xf[t], acc[t]);
+                } else {
+                    acc[0][0] += __uint_as_float((w[0] ^ xf[0][0]) & 1u);       // (keeps the loads alive)
                 }
             }
         };
@@ -135,17 +152,22 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
             issue_w(integral_constant<int, (I + 3) % GR_RW>{}, c + 3);
             compute(integral_constant<int, I>{}, c);
         };
-        for (int base = 0; base < nch; base += GR_RW) {
+        int base = 0;
+        for (; base + GR_RW <= nch; base += GR_RW) {              // (no exit inside a round of the ring: straight-line waits)
             step(integral_constant<int, 0>{}, base);
-            if (base + 1 < nch) step(integral_constant<int, 1>{}, base + 1);
-            if (base + 2 < nch) step(integral_constant<int, 2>{}, base + 2);
-            if (base + 3 < nch) step(integral_constant<int, 3>{}, base + 3);
+            step(integral_constant<int, 1>{}, base + 1);
+            step(integral_constant<int, 2>{}, base + 2);
+            step(integral_constant<int, 3>{}, base + 3);
         }
+        if (base < nch) step(integral_constant<int, 0>{}, base);
+        if (base + 1 < nch) step(integral_constant<int, 1>{}, base + 1);
+        if (base + 2 < nch) step(integral_constant<int, 2>{}, base + 2);
     } else {
         for (int c = 0; c < nch; ++c) bar();                      // idle wave: keeps the barrier count
     }
     // ---- fold the k-groups' accumulators through LDS (slots past nwk hold zeros), then the epilogue: thread group
     // tid / 256 takes tile t0 + tid / 256 (+ 4 in the second round) exactly as a streaming-kernel workgroup would
+    if (probe & 16) { if (acc[0][0] == 123.456f) part[0] = 1.f; return; }
     __syncthreads();
     if (comp) {
 #pragma unroll

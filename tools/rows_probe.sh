@@ -1,8 +1,7 @@
 #!/bin/bash
-# timing probes of the balanced many-row GEMM (results are wrong for probe != 0): which part of an iteration costs what
-for p in 0 1 2 3 4 7; do
-  echo "== SD_ROWS_PROBE=$p"
-  SD_ROWS_PROBE=$p SD_GEMM_ROWS=1 python - <<'PY'
+# Timing of the balanced many-row GEMM at the 13b shapes.  GR_PROBE variants (results wrong, timing only) need a rebuild:
+#   SD_EXTRA_HIPCC_FLAGS=-DGR_PROBE=7 python -m llmspeculativesampling_amd._build --force
+python - <<'PY'
 import os, sys
 sys.path.insert(0, ".")
 sys.argv = ["x"]
@@ -10,7 +9,6 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("gb", "tools/gemm_bench.py")
 gb = importlib.util.module_from_spec(spec); spec.loader.exec_module(gb)
 for n in ("qkv", "o", "gate_up", "down"):
-    for M in (40, 64):
+    for M in (20, 40, 60, 64):
         gb.bench(n, *gb.SHAPES[n], M=M)
 PY
-done
