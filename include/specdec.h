@@ -328,6 +328,10 @@ int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, i
  * ran into its limit leaves a bit in the status word of the LAST forward, read here (blocking copy; 0 = no wait timed out,
  * also when that forward took the launch-per-op path). */
 int sd_session_chain_status(sd_session *s, unsigned *status_out);
+/* Debugging aid: the wall_clock64 (100 MHz) stamps the last fused attention + O-projection launch left when the session
+ * was created under SD_AO_STAMPS=1 (fused_kernels.h): [0,1] attention workgroup 0 start / arrival; [2..6] and [8..12] the O
+ * workgroups of n-tiles 0 and N/32: start, weights landed, counter seen, MFMAs done, slab stored. */
+int sd_session_ao_stamps(sd_session *s, long long *out144 /* 14 + 2 spare + 64 x (start, arrival) of the heads */);
 
 /* Stream-batched forward: the new rows of up to 16 independent sequences share ONE pass over the
  * weights (same bytes streamed, n_items times the tokens).  Each item names its own session (KV arena), its token

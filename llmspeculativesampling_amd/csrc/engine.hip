@@ -13,6 +13,7 @@
 #include "small_kernels.h"
 #include "chain_kernels.h"
 #include "rows_kernels.h"
+#include "fused_kernels.h"
 
 static thread_local char g_err[512] = "";
 void sd_set_error(const char *fmt, ...) {
@@ -44,6 +45,8 @@ struct sd_session {
     void *h2;           // second normalised-operand buffer and the phase counters (+ error word) of the chained layer
     unsigned *chain_ctr;   // launch (chain_kernels.h): [CH_MAX_PHASES][CH_CTR_WORDS] + 32 words, zeroed per forward
     int chain_used;        // the last forward took the chained launches (its status word is meaningful)
+    unsigned *ao_ctr;      // arrival counter of the fused attention + O projection launches (monotonic, fused_kernels.h)
+    unsigned ao_epoch;     // launches counted so far: a launch waits for ao_epoch * n_heads arrivals
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
     int kv_fp8;         // the arena holds fp8 e4m3 (sd_session_set_kv_fp8)
@@ -141,7 +144,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_rows = 1, cus = 0;
+    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -155,6 +158,10 @@ static void refresh_env() {
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
     g_env.attn_split_keys = geti("SD_ATTN_SPLIT_KEYS", 384);          // keys per workgroup above which a group's keys are split
     g_env.attn_keys_per_split = std::max(16, geti("SD_ATTN_KEYS_PER_SPLIT", 256));
+    g_env.ao_stamps = geti("SD_AO_STAMPS", 0);
+    g_env.ao_delay = geti("SD_AO_DELAY", 300);        // 10 ns ticks the O workgroups hold their weight requests back (fused_kernels.h)
+    g_env.ao_gap = geti("SD_AO_GAP", 100);            // ... and pause after every 8 requests
+    g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
     if (!g_env.cus) {
         int dev = 0, n = 0;
@@ -345,7 +352,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, h2, cctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
+    size_t x, x2, h, h2, cctr, aoctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -360,6 +367,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.h = take(trows * wide * es);
     p.h2 = take(trows * wide * es);
     p.cctr = take(((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned));
+    p.aoctr = take(2048);
     p.q = take((size_t)rows * c.hidden * es);
     p.attn = take(trows * c.hidden * es);
     p.act = take(trows * c.inter * es);
@@ -441,6 +449,9 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->h2 = s->scratch + p.h2;
     s->chain_ctr = (unsigned *)(s->scratch + p.cctr);
     s->chain_used = 0;
+    s->ao_ctr = (unsigned *)(s->scratch + p.aoctr);
+    s->ao_epoch = 0;
+    SD_HIP_CHECK(hipMemset(s->ao_ctr, 0, 2048));
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
     s->act = s->scratch + p.act;
@@ -903,6 +914,45 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
 }
 
 
+// Attention + O projection in one launch (fused_kernels.h) for <= 8 rows of one stream on a 16-bit model with
+// head_dim 128 and K = n_heads * 128 <= 5120: returns false when the shape does not qualify (the caller then takes the two
+// launches).  On success the O projection's single slab is in s->part.
+template <typename T>
+static bool attn_oproj_ok(const sd_session *s, const RowTab &tab, int s_max) {
+    const sd_model_config &c = s->m->cfg;
+    if constexpr (sizeof(T) != 2) return false;
+    if (!g_env.fuse_attn_o || g_env.chain || s->tp || tab.tree || tab.kv_fp8 || tab.contig) return false;
+    if (c.head_dim != 128 || tab.n_groups != 1 || tab.n_rows > ATT_TQ) return false;
+    const int K = q_dim(c), N = c.hidden;
+    if (K % 128 || K / 128 > AO_NKW || N % 16 || s_max > g_env.attn_split_keys) return false;
+    const int cus = g_env.cus > 0 ? g_env.cus : 256;
+    if (c.n_heads + (N / 16 + 1) / 2 > cus) return false;         // every workgroup resident at once, one per CU
+    if ((size_t)16 * N > s->part_floats) return false;
+    return true;
+}
+template <typename T>
+static int launch_attn_oproj(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, const void *wo,
+                             hipStream_t st) {
+    const sd_model_config &c = s->m->cfg;
+    constexpr int D = 128;
+    const int s_cap = (int)align_up(s_max, 64);
+    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_oproj_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  80 * 1024);
+        attr = true;
+    }
+    SD_REQUIRE(lds <= 80 * 1024, "attn_oproj: %d keys exceed the two-workgroups-per-CU LDS budget", s_max);
+    s->ao_epoch += 1;
+    const unsigned want = s->ao_epoch * (unsigned)c.n_heads;
+    hipLaunchKernelGGL((attn_oproj_kernel<T>), dim3(c.n_heads + (c.hidden / 16 + 1) / 2), dim3(512), lds, st, q, tab, layer, out, c.n_heads,
+                       c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, (const u32x4 *)wo, s->part, tab.n_rows, c.hidden,
+                       q_dim(c), s->ao_ctr, want, g_env.ao_delay, g_env.ao_gap,
+                       g_env.ao_stamps ? (long long *)(s->ao_ctr + 16) : (long long *)nullptr);
+    return SD_OK;
+}
+
 // ---- small-model decode path (small_kernels.h): 5 launches per layer + the head --------------------------------
 static bool small_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
@@ -1267,7 +1317,18 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                                1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
-        {
+        bool o_done = false;
+        if constexpr (!std::is_same<T, float>::value) {
+            if (attn_oproj_ok<T>(s, tab, s_max)) {
+                ProfScope ps(s, PC_ATTN, st);
+                if ((rc = launch_attn_oproj<T>(s, qb, tab, l, at, s_max, m->wo[l], st)) != SD_OK) return rc;
+                SD_LAUNCH_CHECK();
+                go.S = 1;
+                go.stride_s = (size_t)16 * H;
+                o_done = true;
+            }
+        }
+        if (!o_done) {
             ProfScope ps(s, PC_ATTN, st);
             switch (D) {
                 case 16: rc = launch_attn<T, 16>(s, qb, tab, l, at, s_max, st); break;
@@ -1285,7 +1346,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             }
         }
         // output projection + residual (+ norm feeding the MLP)
-        if ((rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
+        if (!o_done && (rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
         const float *osrc = s->part;
         if ((rc = tp_reduce(s, &go, &osrc, n_new, H, st)) != SD_OK) return rc;
         {
@@ -1533,6 +1594,13 @@ __global__ void kv_compact_kernel(char *kv, int max_seq, int row_bytes, int base
         const int j = i / n16, c = i - j * n16;
         reinterpret_cast<uint4 *>(arena + (size_t)(base + j) * row_bytes)[c] = reinterpret_cast<const uint4 *>(sm)[i];
     }
+}
+
+// debugging aid (tools/ao_stamps.py): the 14 wall_clock64 stamps the last fused attention + O launch left (SD_AO_STAMPS=1)
+extern "C" int sd_session_ao_stamps(sd_session *s, long long *out14) {
+    SD_REQUIRE(s && out14, "sd_session_ao_stamps: null argument");
+    SD_HIP_CHECK(hipMemcpy(out14, s->ao_ctr + 16, (14 + 2 + 128) * sizeof(long long), hipMemcpyDeviceToHost));
+    return SD_OK;
 }
 
 extern "C" int sd_session_chain_status(sd_session *s, unsigned *status_out) {

@@ -1,0 +1,134 @@
+// Attention and the output projection of one decoder layer as ONE launch (single-stream verify / decode rows, 16-bit
+// models; reference modeling_llama.py:346-372 + the o_proj of :388, modeling_opt.py:226-278).
+//
+// Why: after the QKV GEMM a layer runs attention - Hq workgroups on Hq CUs for ~9.6 us at 5 rows x 196 keys, HBM nearly idle -
+// and only then the O projection, a weight stream (52 MB at 13b) that depends on attention's output but whose WEIGHTS do
+// not.  Here the grid is Hq attention workgroups (dispatched first) + one 512-thread workgroup per PAIR of 16-column
+// n-tiles of W_o; each half (four waves) of an O workgroup requests its tile's whole k-range straight away - a quarter per
+// wave, NKW k-steps, register resident (40 x 1 KiB per wave at K = 5120) - so the O matrix streams from HBM WHILE
+// attention runs; then wave 0 polls a device counter the attention workgroups arrive on, the workgroup reads the
+// attention rows, multiplies and leaves ONE split-K slab (SB = 1: the residual+norm kernel folds one slab instead of four).
+// 512 threads at ~240 VGPRs fill a CU's wave slots, so every workgroup has a CU to itself: an attention workgroup (its
+// waves 4..7 exit at once) never shares the per-CU in-order memory pipeline with an O workgroup's 320 KiB of requests -
+// sharing it (the first cut: 256-thread workgroups, two per CU) made the last attention workgroup arrive at 16-17 us
+// instead of ~8 and the launch no faster than two (tools/ao_stamps.py).
+//
+// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"; the form chain_kernels.h uses): the attention rows are
+// stored write-through (sc1, 8-byte stores), every storing wave drains its stores (s_waitcnt vmcnt(0)), a workgroup
+// barrier, then ONE lane adds to the counter (agent scope).  The consumer's first wave polls the counter with agent-scope
+// relaxed loads, the other waves join it at a workgroup barrier, and only then is the first load of the rows issued - a
+// kernel starts with clean caches and no workgroup reads those lines earlier in this launch, so no stale copy exists.
+// The counter is monotonic (target = epoch * Hq, epoch counted by the host per launch): nothing is reset between launches.
+// All Hq + N/16 workgroups are resident at once (two per CU by LDS and registers, checked on the host against the CU
+// count) and the attention workgroups have the lowest block indices, so the wait cannot deadlock; it is still bounded:
+// a wait that exceeds its limit poisons the workgroup's slab with NaN, which the sampler reports as 'norm logits error' -
+// a timed-out launch can never return plausible numbers.
+#pragma once
+#include "model_kernels.h"
+
+#define AO_NKW 40                                             // k-steps a wave keeps in registers (K <= 4 * 32 * AO_NKW = 5120)
+#define AO_XPF 8                                              // activation fragments requested ahead
+#define AO_TIMEOUT_TICKS 2000000ll                            // wall_clock64 runs at 100 MHz: 20 ms
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
+                                                           T *__restrict__ attn_out, int Hq, int Hkv, int arch,
+                                                           float inv_sqrt_d, int s_cap, const u32x4 *__restrict__ Wo,
+                                                           float *__restrict__ part, int M, int N, int K,
+                                                           unsigned *__restrict__ ctr, unsigned want,
+                                                           int delay_ticks, int gap_ticks, long long *__restrict__ stamps) {
+    // stamps (or NULL; SD_AO_STAMPS=1, tools/ao_stamps.py): wall_clock64 at the milestones of attention workgroup 0 and of
+    // the O workgroups of n-tiles 0 and N/32 - where the launch's time goes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    auto stamp = [&](int slot) { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); };
+    if ((int)blockIdx.x < Hq) {
+        if (threadIdx.x >= 256) return;                           // (an ended wave is not counted by the barriers below)
+        if (blockIdx.x == 0) stamp(0);
+        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x);           // ... and start
+        // ---- attention of head blockIdx.x (one row group, whole key range), rows stored write-through ----
+        attn_body<T, 128, false, false, true>(qbuf, tab, layer, attn_out, Hq, Hkv, arch, inv_sqrt_d, s_cap, 1, nullptr,
+                                              (int)blockIdx.x, 0, 0, smem);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0) stamp(1);
+        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x + 1);       // every head's arrival ...
+        return;
+    }
+    // ---- O projection of n-tiles 2 b and 2 b + 1 (b = blockIdx.x - Hq): 4 waves x a quarter of K each, weights first ----
+    const int half = (int)(threadIdx.x >> 8), tid4 = (int)(threadIdx.x & 255);
+    f32x4 (*red)[1][64] = reinterpret_cast<f32x4 (*)[1][64]>(smem) + half * 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(tid4 >> 6);
+    const int KS = K >> 5, ntg_raw = 2 * ((int)blockIdx.x - Hq) + half;
+    const bool has_tile = ntg_raw < (N >> 4);
+    const int ntg = has_tile ? ntg_raw : 0;
+    const int sbase = ntg_raw == 0 ? 2 : (ntg_raw == (N >> 5) ? 8 : -1);  // stamp slots of the two observed O tiles
+    auto ostamp = [&](int i) { if (sbase >= 0 && stamps && tid4 == 0) stamps[sbase + i] = wall_clock64(); };
+    ostamp(0);
+    const int per = (KS + 3) >> 2;                                // gemm_bf16_stream's quarters (SB = 1)
+    const int ks0 = min(KS, wv * per), ks1 = min(KS, ks0 + per), nk = ks1 - ks0, dlast = max(nk - 1, 0);
+    const u32x4 *wp = Wo + ((size_t)ntg * KS + min(ks0, KS - 1)) * 64 + lane;
+    // Pacing of the weight requests (10 ns ticks): a hold-back before the first request and a pause after every 8 (defaults
+    // 3 us / 1 us, SD_AO_DELAY / SD_AO_GAP).  Measured with the stamps (tools/ao_stamps.py, 13b layer, 5 rows x 195 keys,
+    // cold caches, profiles/r03_attn_oproj_stamps.txt): requested at once the 52 MB land in 6.5-7.5 us and every
+    // attention workgroup arrives at 10.6-15 us instead of ~8 - its K / V loads queue behind the stream; held back 3.5 us,
+    // half of the attention workgroups arrive at 9.4-10 us (undisturbed) and the other half at 13-14.7 us, the weights at
+    // 8-9 us.  The launch ends at 17.5-19 us against 9.6 + 1.7 + 10.4 for the two launches: 0.15-0.2 ms per verify, not
+    // the ~0.35 ms a uniformly undisturbed attention would give.  What delays the second half is the open item.
+    if (delay_ticks > 0) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < delay_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    u32x4 w[AO_NKW];
+#pragma unroll
+    for (int u = 0; u < AO_NKW; ++u) {                            // (no branch around a load; a k-step past the range is
+        w[u] = __builtin_nontemporal_load(wp + (size_t)min(u, dlast) * 64);   //  multiplied as zero below)
+        asm volatile("" ::: "memory");
+        if ((u & 7) == 7 && gap_ticks > 0 && u + 1 < AO_NKW) {
+            const long long t1 = wall_clock64();
+            while (wall_clock64() - t1 < gap_ticks) __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    // ---- wait for the Hq attention workgroups of this launch.  The polling wave first waits for its OWN weights: N/16
+    // waves polling one word from t = 0 are a request storm on one memory channel that the attention workgroups' K / V
+    // loads have to get through (measured: with it attention arrived at 11-17 us instead of ~8, whatever the prefetch did)
+    bool timed_out = false;
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ostamp(1);
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned got = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(got - want) >= 0) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > AO_TIMEOUT_TICKS) { timed_out = true; break; }
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    ostamp(2);
+    // operand layout (xoff): tile (0, ks) = 512 elements, lane 16 * quad + m holds X[m][32 ks + 8 quad .. + 8); lanes of
+    // rows >= M read row 0's fragment (their results land in output columns the epilogue drops)
+    const int mrow = (lane & 15) < M ? (lane & 15) : 0;
+    const T *xp = attn_out + (size_t)min(ks0, KS - 1) * 512 + ((lane >> 4) * 16 + mrow) * 8;
+    auto ldx = [&](int k) -> u32x4 { return *reinterpret_cast<const u32x4 *>(xp + (size_t)min(k, dlast) * 512); };
+    u32x4 x[AO_XPF];
+#pragma unroll
+    for (int u = 0; u < AO_XPF; ++u) x[u] = ldx(u);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < AO_NKW; ++u) {
+        u32x4 wu = w[u];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wu[q] = u < nk ? wu[q] : 0u;
+        acc = mfma16<T>(wu, x[u % AO_XPF], acc);                  // k-steps in order: the streaming kernel's sum
+        if (u + AO_XPF < AO_NKW) x[u % AO_XPF] = ldx(u + AO_XPF);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)timed_out)) acc = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+    red[wv][0][lane] = acc;
+    ostamp(3);
+    __syncthreads();
+    GemmEpiT<T> e = {};
+    if (has_tile) gemm_epilogue_step<1, EPI_PART, 1, 1, T>(red, 0, part, M, 16, N, 0, ntg, e, tid4);
+    ostamp(4);
+}

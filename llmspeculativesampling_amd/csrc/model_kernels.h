@@ -909,21 +909,22 @@ __device__ long long g_att_stamps[16];
 #endif
 // KV8: the arena holds fp8 e4m3 (tab.kv_fp8; 16-bit T and D >= 32 only): keys / values are widened to T in registers
 // (exact), the K scale multiplies the scores and the V scale the output.
-template <typename T, int D, bool KV8 = false, bool TREE = false>
-__global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
-                                                  T *__restrict__ out, int Hq, int Hkv, int arch,
-                                                  float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
+// The body of one attention workgroup = (head, row group bg, key split bz); WT: the output rows are stored write-through
+// (sc1) because another workgroup of the SAME launch reads them (attn_oproj_kernel).
+template <typename T, int D, bool KV8, bool TREE, bool WT>
+__device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowTab &tab, int layer, T *__restrict__ out, int Hq,
+                                          int Hkv, int arch, float inv_sqrt_d, int s_cap, int nsplit,
+                                          float *__restrict__ partial, int head, int bg, int bz, char *smem) {
     static_assert(!KV8 || (sizeof(T) == 2 && D >= 32), "fp8 KV needs a 16-bit model type and the MFMA score path");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     constexpr int ATT_RG = 256 / (D / 8);                         // key groups of the P.V phase, each leaves a partial sum
     float *red = qs + ATT_TQ * D;                                 // [ATT_RG][TQ][D]
     float *sc = red + ATT_RG * ATT_TQ * D;                        // [TQ][s_cap]
     // one group = up to ATT_TQ consecutive rows of one stream; "pos0 + r0" below is the position of its first row
-    const int head = blockIdx.x, r0 = tab.grp_row0[blockIdx.y];
-    const int nr = tab.grp_n[blockIdx.y];
-    const int strm = tab.grp_stream[blockIdx.y], max_seq = tab.max_seq[strm];
-    const int pos0 = tab.grp_pos[blockIdx.y] - r0;
+    const int r0 = tab.grp_row0[bg];
+    const int nr = tab.grp_n[bg];
+    const int strm = tab.grp_stream[bg], max_seq = tab.max_seq[strm];
+    const int pos0 = tab.grp_pos[bg] - r0;
     const int kvh = head / (Hq / Hkv);
     const T *karena = (const T *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
     const unsigned char *karena8 = (const unsigned char *)tab.kv_base[strm] + (size_t)layer * 2 * Hkv * max_seq * D;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     constexpr bool tree = TREE;                                   // (a template flag: the causal path pays nothing for it)
     const int s_all = tree ? tab.tree_base + tab.n_rows : pos0 + r0 + nr;   // keys visible to the last row of the group
     const int chunk = nsplit > 1 ? (((s_all + nsplit - 1) / nsplit + 15) & ~15) : s_all;
-    const int kb = nsplit > 1 ? (int)blockIdx.z * chunk : 0;
+    const int kb = nsplit > 1 ? bz * chunk : 0;
     const int s_hi = max(0, min(s_all, kb + chunk) - kb);
     const int vis0 = pos0 + r0 - kb;                              // local index of the last key row t = 0 may see
     auto vis = [&](int t, int s) -> bool {                        // may row t of the group see local key s?
@@ -1239,7 +1240,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
     __syncthreads();
     ATT_STAMP(6);
     if (nsplit > 1) {
-        float *pz = partial + (((size_t)blockIdx.y * Hq + head) * nsplit + blockIdx.z) * ATT_TQ * (D + 2);
+        float *pz = partial + (((size_t)bg * Hq + head) * nsplit + bz) * ATT_TQ * (D + 2);
         for (int i = tid; i < nr * D; i += 256) {
             const int t = i / D, d = i - t * D;
             float a = 0.f;
@@ -1250,14 +1251,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, R
         if (tid < nr) { pz[(size_t)tid * (D + 2) + D] = ml[tid][0]; pz[(size_t)tid * (D + 2) + D + 1] = ml[tid][1]; }
         return;
     }
-    for (int i = tid; i < nr * D; i += 256) {
-        const int t = i / D, d = i - t * D;
-        float a = 0.f;
+    if constexpr (sizeof(T) == 2 && D % 4 == 0) {
+        // four consecutive head dims per thread: one 8-byte store (inside an 8-element group of the operand layout)
+        for (int i = tid; i < nr * (D / 4); i += 256) {
+            const int t = i / (D / 4), d = (i - t * (D / 4)) * 4;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
-        out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(KV8 ? a * v_scale : a);
+            for (int g = 0; g < ATT_RG; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] += red[((size_t)g * ATT_TQ + t) * D + d + c];
+            if constexpr (KV8) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] *= v_scale;
+            }
+            store4_maybe_wt<WT>(out + xoff<T>(r0 + t, head * D + d, Hq * D), a[0], a[1], a[2], a[3]);
+        }
+    } else {
+        for (int i = tid; i < nr * D; i += 256) {
+            const int t = i / D, d = i - t * D;
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < ATT_RG; ++g) a += red[((size_t)g * ATT_TQ + t) * D + d];
+            out[xoff<T>(r0 + t, head * D + d, Hq * D)] = from_f<T>(KV8 ? a * v_scale : a);
+        }
     }
     ATT_STAMP(7);
+}
+
+template <typename T, int D, bool KV8 = false, bool TREE = false>
+__global__ __launch_bounds__(256) void attn_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
+                                                  T *__restrict__ out, int Hq, int Hkv, int arch,
+                                                  float inv_sqrt_d, int s_cap, int nsplit, float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_body<T, D, KV8, TREE, false>(qbuf, tab, layer, out, Hq, Hkv, arch, inv_sqrt_d, s_cap, nsplit, partial, (int)blockIdx.x,
+                                      (int)blockIdx.y, (int)blockIdx.z, smem);
 }
 
 // out = sum_z acc_z * exp(m_z - M) / sum_z l_z * exp(m_z - M): merges the nsplit key chunks of one (head, group)
