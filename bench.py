@@ -59,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--accept-sweep", type=int, default=1,
                     help="after the headline, time the same workload on the acceptance-dial pair at each --sweep-sigmas (N=1)")
     ap.add_argument("--sweep-sigmas", default="0,0.04,0.08,0.16,0.32,1.0")
-    ap.add_argument("--sweep-steps", type=int, default=2)
+    ap.add_argument("--sweep-steps", type=int, default=4)
     ap.add_argument("--tp", type=int, default=1,
                     help="tensor-parallel degree of the TARGET (BASELINE config 5: --target llama-2-70b --tp 8 --kv-dtype fp8): "
                          "all --gpus ranks then decode ONE stream per step together (tp must equal gpus)")

@@ -44,10 +44,11 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     if ((int)blockIdx.x < Hq) {
         if (threadIdx.x >= 256) return;                           // (an ended wave is not counted by the barriers below)
         if (blockIdx.x == 0) stamp(0);
-        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x);           // ... and start
+        // (stamped runs: every head's time when its stores are ISSUED, then when they are acknowledged and counted)
         // ---- attention of head blockIdx.x (one row group, whole key range), rows stored write-through ----
         attn_body<T, 128, false, false, true>(qbuf, tab, layer, attn_out, Hq, Hkv, arch, inv_sqrt_d, s_cap, 1, nullptr,
                                               (int)blockIdx.x, 0, 0, smem);
+        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have left
         __syncthreads();
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

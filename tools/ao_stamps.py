@@ -27,8 +27,7 @@ for rep in range(4):
     t0 = t[0]
     print(f"rep {rep}: attention wg0: start 0.0, arrived {t[1]-t0:.2f} us")
     heads = [((st[16 + 2 * h] / 100.0) - t0, (st[16 + 2 * h + 1] / 100.0) - t0) for h in range(40)]
-    print("   attention heads: start min/max %.2f/%.2f us; arrival sorted:" % (min(a for a, _ in heads), max(a for a, _ in heads)),
-          " ".join("%.1f" % b for _, b in sorted(heads, key=lambda x: x[1])))
+    print("   attention heads (stores issued -> counted), by head:", " ".join("%.1f->%.1f" % (a, b) for a, b in heads))
     for name, b in (("O tile 0", 2), ("O tile N/32", 8)):
         print(f"   {name}: start {t[b]-t0:.2f}, weights landed {t[b+1]-t0:.2f}, counter seen {t[b+2]-t0:.2f}, "
               f"MFMAs done {t[b+3]-t0:.2f}, slab stored {t[b+4]-t0:.2f}")

@@ -83,7 +83,7 @@ def main():
     # grid 2000 workgroups (N = 32000) and K = 5120 (target): dispatches with grid 2000*256 alternate draft / target;
     # simpler and robust: total over all dispatches of target-sized kernels divided by the number of verify steps.
     n_verify = sum(1 for (_, k, g, v) in frows if is_gu(k, g)) // layers
-    ours = ("gemm_bf16_stream<1", "gemm_small", "attn_kernel", "residual_norm", "norm_probs", "logits_kernel", "embed_kernel",
+    ours = ("gemm_bf16_stream<1", "gemm_small", "attn_kernel", "attn_oproj_kernel", "residual_norm", "norm_probs", "logits_kernel", "embed_kernel",
             "norm_kernel", "sample_kernel", "accept_scan", "qkv_epilogue", "act_kernel")
     tgt_f = sum(v for (_, k, g, v) in frows if any(o in k for o in ours)) * 1024 * 2
     tgt_w = sum(v for (_, k, g, v) in wrows if any(o in k for o in ours)) * 1024
