@@ -46,7 +46,7 @@ struct sd_session {
     unsigned *chain_ctr;   // launch (chain_kernels.h): [CH_MAX_PHASES][CH_CTR_WORDS] + 32 words, zeroed per forward
     int chain_used;        // the last forward took the chained launches (its status word is meaningful)
     unsigned *ao_ctr;      // arrival counter of the fused attention + O projection launches (monotonic, fused_kernels.h)
-    unsigned ao_epoch;     // launches counted so far: a launch waits for ao_epoch * n_heads arrivals
+    unsigned ao_epoch;     // arrivals expected so far (wraps; compared as a signed difference)
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
     int kv_fp8;         // the arena holds fp8 e4m3 (sd_session_set_kv_fp8)
@@ -922,11 +922,11 @@ static bool attn_oproj_ok(const sd_session *s, const RowTab &tab, int s_max) {
     const sd_model_config &c = s->m->cfg;
     if constexpr (sizeof(T) != 2) return false;
     if (!g_env.fuse_attn_o || g_env.chain || s->tp || tab.tree || tab.kv_fp8 || tab.contig) return false;
-    if (c.head_dim != 128 || tab.n_groups != 1 || tab.n_rows > ATT_TQ) return false;
+    if (c.head_dim != 128 || tab.n_groups > 2 || tab.n_streams != 1 || tab.n_rows > 16) return false;
     const int K = q_dim(c), N = c.hidden;
     if (K % 128 || K / 128 > AO_NKW || N % 16 || s_max > g_env.attn_split_keys) return false;
     const int cus = g_env.cus > 0 ? g_env.cus : 256;
-    if (c.n_heads + (N / 16 + 1) / 2 > cus) return false;         // every workgroup resident at once, one per CU
+    if (c.n_heads * tab.n_groups + (N / 16 + 1) / 2 > cus) return false;      // every workgroup resident at once, one per CU
     if ((size_t)16 * N > s->part_floats) return false;
     return true;
 }
@@ -944,9 +944,9 @@ static int launch_attn_oproj(sd_session *s, const T *q, const RowTab &tab, int l
         attr = true;
     }
     SD_REQUIRE(lds <= 80 * 1024, "attn_oproj: %d keys exceed the two-workgroups-per-CU LDS budget", s_max);
-    s->ao_epoch += 1;
-    const unsigned want = s->ao_epoch * (unsigned)c.n_heads;
-    hipLaunchKernelGGL((attn_oproj_kernel<T>), dim3(c.n_heads + (c.hidden / 16 + 1) / 2), dim3(512), lds, st, q, tab, layer, out, c.n_heads,
+    s->ao_epoch += (unsigned)(c.n_heads * tab.n_groups);         // arrivals counted so far, this launch's included
+    const unsigned want = s->ao_epoch;
+    hipLaunchKernelGGL((attn_oproj_kernel<T>), dim3(c.n_heads * tab.n_groups + (c.hidden / 16 + 1) / 2), dim3(512), lds, st, q, tab, layer, out, c.n_heads,
                        c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, (const u32x4 *)wo, s->part, tab.n_rows, c.hidden,
                        q_dim(c), s->ao_ctr, want, g_env.ao_delay, g_env.ao_gap,
                        g_env.ao_stamps ? (long long *)(s->ao_ctr + 16) : (long long *)nullptr);

@@ -1,4 +1,5 @@
-// Attention and the output projection of one decoder layer as ONE launch (single-stream verify / decode rows, 16-bit
+// Attention and the output projection of one decoder layer as ONE launch (single-stream verify / decode rows - up to 16,
+// i.e. two attention row groups: gamma <= 15 -, 16-bit
 // models; reference modeling_llama.py:346-372 + the o_proj of :388, modeling_opt.py:226-278).
 //
 // Why: after the QKV GEMM a layer runs attention - Hq workgroups on Hq CUs for ~9.6 us at 5 rows x 196 keys, HBM nearly idle -
@@ -18,7 +19,8 @@
 // barrier, then ONE lane adds to the counter (agent scope).  The consumer's first wave polls the counter with agent-scope
 // relaxed loads, the other waves join it at a workgroup barrier, and only then is the first load of the rows issued - a
 // kernel starts with clean caches and no workgroup reads those lines earlier in this launch, so no stale copy exists.
-// The counter is monotonic (target = epoch * Hq, epoch counted by the host per launch): nothing is reset between launches.
+// The counter is monotonic (the host passes the number of arrivals expected so far, this launch's included; compared as
+// a signed difference so it may wrap): nothing is reset between launches.
 // All Hq + N/16 workgroups are resident at once (two per CU by LDS and registers, checked on the host against the CU
 // count) and the attention workgroups have the lowest block indices, so the wait cannot deadlock; it is still bounded:
 // a wait that exceeds its limit poisons the workgroup's slab with NaN, which the sampler reports as 'norm logits error' -
@@ -41,13 +43,14 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     // the O workgroups of n-tiles 0 and N/32 - where the launch's time goes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     auto stamp = [&](int slot) { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); };
-    if ((int)blockIdx.x < Hq) {
+    const int n_att = Hq * tab.n_groups;                          // attention workgroups: (head, row group), head fastest
+    if ((int)blockIdx.x < n_att) {
         if (threadIdx.x >= 256) return;                           // (an ended wave is not counted by the barriers below)
         if (blockIdx.x == 0) stamp(0);
         // (stamped runs: every head's time when its stores are ISSUED, then when they are acknowledged and counted)
         // ---- attention of head blockIdx.x (one row group, whole key range), rows stored write-through ----
         attn_body<T, 128, false, false, true>(qbuf, tab, layer, attn_out, Hq, Hkv, arch, inv_sqrt_d, s_cap, 1, nullptr,
-                                              (int)blockIdx.x, 0, 0, smem);
+                                              (int)blockIdx.x % Hq, (int)blockIdx.x / Hq, 0, smem);
         if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have left
         __syncthreads();
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     const int half = (int)(threadIdx.x >> 8), tid4 = (int)(threadIdx.x & 255);
     f32x4 (*red)[1][64] = reinterpret_cast<f32x4 (*)[1][64]>(smem) + half * 4;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(tid4 >> 6);
-    const int KS = K >> 5, ntg_raw = 2 * ((int)blockIdx.x - Hq) + half;
+    const int KS = K >> 5, ntg_raw = 2 * ((int)blockIdx.x - n_att) + half;
     const bool has_tile = ntg_raw < (N >> 4);
     const int ntg = has_tile ? ntg_raw : 0;
     const int sbase = ntg_raw == 0 ? 2 : (ntg_raw == (N >> 5) ? 8 : -1);  // stamp slots of the two observed O tiles

@@ -987,8 +987,8 @@ def test_fused_attention_oproj_launch_vs_two_launches(hip):
     shape (2 layers): K / V rows are bit-identical (they do not depend on the O projection); logits agree within the bf16
     bar of the other forward tests - the fused O projection folds ONE k-slab where the streaming kernel folds four - and,
     the point of the exercise, twenty repetitions of the same steps give bit-identical results every time: a stale read
-    of the attention rows across XCDs would show up as run-to-run differences.  Steps of 1, 5 and 8 rows take the fused
-    launch, the 9-row step and the prefill do not (two row groups / 256 rows)."""
+    of the attention rows across XCDs would show up as run-to-run differences.  Steps of 1 - 9 rows take the fused
+    launch (the 9-row step with two attention row groups), the 200-row prefill does not."""
     cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
                       num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, rms_norm_eps=1e-5)
     m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=400)

@@ -47,10 +47,10 @@ def _host_sd(m):
     return sd
 
 
-def _truth_errors(hip, cfg, seed, label):
+def _truth_errors(hip, cfg, seed, label, transform=None):
     """HIP bf16 forward and oracle bf16 forward against the oracle fp32 forward of the same bf16-valued weights:
     a 23-row prefill, then a gamma+1 = 5-row verify whose logits are compared.  Returns the oracle's bf16 logits too."""
-    m = hip.engine.SpecDecModel.synthetic(cfg, seed=seed, dtype=torch.bfloat16, max_pos=64)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=seed, dtype=torch.bfloat16, max_pos=64, transform=transform)
     sd16 = _host_sd(m)
     ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 28)))
     ses = m.new_session(64)
@@ -103,7 +103,12 @@ def test_opt13b_config3_first_verify_vs_oracle_full_size(hip):
     oracle.norm_logits of the oracle's bf16 logits: wherever the two bf16 logit rows agree on the top-20 set, the
     supports must be identical up to ties at the cut, and the draft's prefill + step likewise."""
     tcfg, dcfg = load_config("opt-13b"), load_config("opt-125m")
-    got, ref16, truth, errs = _truth_errors(hip, tcfg, seed=2, label="opt-13b")
+
+    def soft_head(name, t):
+        # OPT ties its head to the (std 1) embedding table: at hidden 5120 that makes logits of several hundred and one-hot
+        # probability rows, which would leave the probability-space check below with nothing to compare
+        return t * 0.0625 if name.endswith("embed_tokens.weight") else t
+    got, ref16, truth, errs = _truth_errors(hip, tcfg, seed=2, label="opt-13b", transform=soft_head)
     _assert_within_reference_error(errs, "opt-13b")
     # OPT's logits are bf16 values (modeling_opt.py:974): the HIP rows must already be rounded
     assert torch.equal(got, got.to(torch.bfloat16).float())
@@ -122,7 +127,7 @@ def test_opt13b_config3_first_verify_vs_oracle_full_size(hip):
         tv_ref = 0.5 * float((p_ref - p_true).abs().sum())
         print(f"opt-13b row {i}: TV to the truth's row: hip {tv_hip:.3f}, ref-bf16 {tv_ref:.3f}")
         assert tv_hip <= 1.5 * tv_ref + 0.05, (i, tv_hip, tv_ref)
-    _, _, _, derrs = _truth_errors(hip, dcfg, seed=1, label="opt-125m")
+    _, _, _, derrs = _truth_errors(hip, dcfg, seed=1, label="opt-125m", transform=soft_head)
     _assert_within_reference_error(derrs, "opt-125m")
 
 
