@@ -97,8 +97,12 @@ struct ChainEpi {
 // Arrivals are counted on min(CH_SHARDS, nblk) counters (workgroup b of the phase adds to counter b % n, without waiting
 // for the add to return); a waiter's first wave reads all of them with one load (lane i: counter i) until each shows its
 // share of the phase's workgroups times `epoch`.
-__device__ __forceinline__ void chain_wait(unsigned *ctr, int slot, int nblk, unsigned epoch, unsigned *err) {
+// `late` (or NULL): an LDS word that is set when the wait ran into its limit; the caller poisons what it produces, so a
+// launch that carried on with stale operands can never hand back plausible numbers (the two-phase launches of the default
+// path, which nobody checks a status word after).
+__device__ __forceinline__ void chain_wait(unsigned *ctr, int slot, int nblk, unsigned epoch, unsigned *err, int *late = nullptr) {
     if (slot < 0) return;
+    if (late && threadIdx.x == 0) *late = 0;
     if (threadIdx.x < 64) {
         const int nsh = min(CH_SHARDS, nblk), lane = threadIdx.x;
         unsigned *mine = ctr + (size_t)slot * CH_CTR_WORDS + (lane < nsh ? lane : 0) * CH_SHARD_STRIDE;
@@ -109,7 +113,10 @@ __device__ __forceinline__ void chain_wait(unsigned *ctr, int slot, int nblk, un
             if (__all(got >= want)) break;
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > CH_TIMEOUT_TICKS) {
-                if (lane == 0) __hip_atomic_fetch_or(err, 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    __hip_atomic_fetch_or(err, 1u << slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (late) *late = 1;
+                }
                 break;
             }
         }
@@ -138,7 +145,8 @@ __device__ __forceinline__ void chain_signal(unsigned *ctr, int slot, int b, int
 // gemm_bf16_stream<1, ., EPI, 1>'s workgroup (one 16-column n-tile x one k-slab, 4 waves on a quarter of the slab each,
 // k-steps accumulated in order), with the weight requests ahead of the wait and kept CH_PF deep afterwards.
 template <int EPI, typename H>
-__device__ __forceinline__ void chain_gemm(const ChainPhase &ph, const ChainArgs<H> &a, int b, f32x4 (*red)[1][64]) {
+__device__ __forceinline__ void chain_gemm(const ChainPhase &ph, const ChainArgs<H> &a, int b, f32x4 (*red)[1][64],
+                                           int *late = nullptr) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = ph.N, KS = ph.K >> 5, NTG = N >> 4;
     const int sb = b / NTG, ntg = b - sb * NTG;
@@ -151,7 +159,8 @@ __device__ __forceinline__ void chain_gemm(const ChainPhase &ph, const ChainArgs
 #pragma unroll
     for (int u = 0; u < CH_PF; ++u) w[u] = u < nk ? __builtin_nontemporal_load(wp + (size_t)u * 64) : u32x4{0u, 0u, 0u, 0u};
 
-    if (!(a.flags & 4)) chain_wait(a.ctr, ph.wait_slot, ph.wait_n, a.epoch, a.err);
+    if (!(a.flags & 4)) chain_wait(a.ctr, ph.wait_slot, ph.wait_n, a.epoch, a.err, late);
+    const bool poisoned = late && *late;
 
     // operand layout (xoff): tile (0, ks) = 512 elements, lane 16 * quad + m holds X[m][32 ks + 8 quad .. + 8).  Lanes of
     // rows >= M read row 0's fragment (the same 16 bytes as their quad's first lane: no extra traffic, no branch around
@@ -184,6 +193,7 @@ __device__ __forceinline__ void chain_gemm(const ChainPhase &ph, const ChainArgs
             }
         }
     }
+    if (poisoned) acc[0] = __uint_as_float(0x7fc00000u);
     red[wv][0][lane] = acc;
     __syncthreads();
     const ChainEpi<H> e = {(H *)ph.out, (const H *)ph.bias, ph.n_out, a.cos_t, a.sin_t, a.Hq, a.Hkv, a.D, ph.layer, a.q_scale, a.tab};
@@ -310,9 +320,9 @@ __global__ __launch_bounds__(256, CH_WAVES) void chain_kernel(ChainArgs<H> a) {
         chain_rn<H, KIND>(ph, a, b, sh);
         if (!(a.flags & 8)) chain_signal(a.ctr, ph.sig_slot, b, ph.nblk, a.epoch, true, (a.flags & 1) != 0);
     }
-    else if (ph.epi == EPI_PART) chain_gemm<EPI_PART, H>(ph, a, b, red);
-    else if (ph.epi == EPI_ACT) chain_gemm<EPI_ACT, H>(ph, a, b, red);
-    else chain_gemm<EPI_QKV, H>(ph, a, b, red);
+    else if (ph.epi == EPI_PART) chain_gemm<EPI_PART, H>(ph, a, b, red, reinterpret_cast<int *>(&sh[31]));
+    else if (ph.epi == EPI_ACT) chain_gemm<EPI_ACT, H>(ph, a, b, red, reinterpret_cast<int *>(&sh[31]));
+    else chain_gemm<EPI_QKV, H>(ph, a, b, red, reinterpret_cast<int *>(&sh[31]));
 }
 
 // Two-level arrival (the engine): arriver g of n_arrive adds 1 to shard counter g % nsh; the last arriver of a shard adds
