@@ -6,7 +6,7 @@ throughput-mode gather of the generated ids at the end (RCCL over xGMI on the GP
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -69,10 +69,28 @@ class TokenComm:
 _COMMS = {}
 
 
-def _token_comm(group, device) -> "TokenComm":
+def _token_comm(group, device) -> Optional["TokenComm"]:
+    """The rank's TokenComm for this process group, or None when it could not be created on EVERY rank (the ranks agree
+    through one all_reduce, so they all take the same collective; the reason goes to stderr)."""
+    import sys
+    import torch.distributed as dist
     key = (id(group), str(device))
     if key not in _COMMS:
-        _COMMS[key] = TokenComm(group, device)
+        comm, err = None, None
+        try:
+            comm = TokenComm(group, device)
+        except Exception as e:                                   # e.g. librccl not resolvable from libspecdec
+            err = e
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok) == 0:
+            if err is not None:
+                print(f"[dist] sd_comm_init failed on this rank ({type(err).__name__}: {err}); "
+                      "gathering through torch.distributed's RCCL all_gather instead", file=sys.stderr, flush=True)
+            if comm is not None:
+                comm.close()
+            comm = None
+        _COMMS[key] = comm
     return _COMMS[key]
 
 
@@ -90,8 +108,9 @@ def gather_streams(outs: Sequence[torch.Tensor], n_streams: int, width: int, dev
     if mine.shape[0] < per_rank:                      # ragged tail: pad with an all -1 row
         pad = torch.full((per_rank - mine.shape[0], width), -1, dtype=torch.int32, device=device)
         mine = torch.cat([mine, pad], 0)
-    if dist.get_backend(group) == "nccl" and mine.is_cuda:
-        gathered = _token_comm(group, mine.device).all_gather_tokens(mine.contiguous())
+    comm = _token_comm(group, mine.device) if dist.get_backend(group) == "nccl" and mine.is_cuda else None
+    if comm is not None:
+        gathered = comm.all_gather_tokens(mine.contiguous())
     else:
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine, group=group)
