@@ -263,3 +263,36 @@ def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac,
     got2, gd2 = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 16, details=True, verbose=True,
                                            rng=hip.noise.DeviceNoise(4242 + seed), **kw)
     assert torch.equal(got, got2) and gd["acc_len"] == gd2["acc_len"]
+
+
+@pytest.mark.parametrize("n_streams", [8, 12], ids=["40rows", "60rows"])
+def test_stream_batched_verify_13b_layer_shape_error_vs_fp32_truth(hip, n_streams):
+    """Throughput mode at the production layer shape ("a bf16 batched-vs-oracle test"): 8 / 12 streams
+    x (gamma + 1) = 40 / 60 verify rows through ONE pass of a 2-layer model with Llama-2-13b's layer shape - the balanced
+    many-row GEMM (gemm_bf16_rows) with its fused QKV / SiLU epilogues, per-stream attention groups, batched prefill of the
+    prompts - against the oracle run stream by stream.  Bar: per stream, the HIP logits' error against an fp32 forward of
+    the same bf16-valued weights is at most 1.5x the error of the reference's bf16 arithmetic (the rule of this file)."""
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=256, rms_norm_eps=1e-5)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=96)
+    sd16 = _host_sd(m)
+    sd32 = {k: v.float() for k, v in sd16.items()}
+    o16, o32 = oracle.RefCausalLM(cfg, sd16), oracle.RefCausalLM(cfg, sd32)
+    rng = np.random.default_rng(21)
+    lens = [int(x) for x in rng.integers(9, 40, size=n_streams)]
+    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(L + 5,)).astype(np.int32)).cuda() for L in lens]
+    sessions = [m.new_session(96) for _ in lens]
+    hip.engine.batch_prefill(sessions, seqs, lens)
+    got = hip.engine.batch_forward(sessions, seqs, [5] * n_streams, [5] * n_streams).cpu()
+    worst = (0.0, 0.0)
+    for i, (L, sq) in enumerate(zip(lens, seqs)):
+        ids = sq[None].long().cpu()
+        ref16 = o16(ids).logits.float()[0, L:L + 5]
+        truth = o32(ids).logits.float()[0, L:L + 5]
+        mine = got[5 * i:5 * i + 5]
+        e_hip, e_ref = float((mine - truth).abs().max()), float((ref16 - truth).abs().max())
+        r_hip, r_ref = float((mine - truth).pow(2).mean().sqrt()), float((ref16 - truth).pow(2).mean().sqrt())
+        worst = max(worst, (e_hip / max(e_ref, 1e-9), r_hip / max(r_ref, 1e-9)))
+        assert r_hip <= 1.5 * r_ref + 1e-3, (i, L, r_hip, r_ref)
+        assert e_hip <= 1.5 * e_ref + 0.02, (i, L, e_hip, e_ref)
+    print(f"{n_streams} streams: worst (max-error ratio, rms ratio) HIP / reference-bf16 = ({worst[0]:.2f}, {worst[1]:.2f})")
