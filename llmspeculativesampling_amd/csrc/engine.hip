@@ -14,6 +14,7 @@
 #include "chain_kernels.h"
 #include "rows_kernels.h"
 #include "fused_kernels.h"
+#include "normload_kernels.h"
 
 static thread_local char g_err[512] = "";
 void sd_set_error(const char *fmt, ...) {
@@ -47,6 +48,7 @@ struct sd_session {
     int chain_used;        // the last forward took the chained launches (its status word is meaningful)
     unsigned *ao_ctr;      // arrival counter of the fused attention + O projection launches (monotonic, fused_kernels.h)
     unsigned ao_epoch;     // arrivals expected so far (wraps; compared as a signed difference)
+    float *ssq;            // [16][hidden / 16] per-tile sums of squares left by a residual epilogue (normload_kernels.h)
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
     int kv_fp8;         // the arena holds fp8 e4m3 (sd_session_set_kv_fp8)
@@ -144,7 +146,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100;
+    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 1;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -162,6 +164,7 @@ static void refresh_env() {
     g_env.ao_delay = geti("SD_AO_DELAY", 300);        // 10 ns ticks the O workgroups hold their weight requests back (fused_kernels.h)
     g_env.ao_gap = geti("SD_AO_GAP", 100);            // ... and pause after every 8 requests
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
+    g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 1);  // 0: residual+norm stays a launch of its own (A/B runs, compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
     if (!g_env.cus) {
         int dev = 0, n = 0;
@@ -352,7 +355,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, h2, cctr, aoctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
+    size_t x, x2, h, h2, cctr, aoctr, ssq, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -368,6 +371,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.h2 = take(trows * wide * es);
     p.cctr = take(((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned));
     p.aoctr = take(2048);
+    p.ssq = take((size_t)16 * (c.hidden / 16 + 1) * sizeof(float));      // per-tile sums of squares of <= 16 rows (norm on load)
     p.q = take((size_t)rows * c.hidden * es);
     p.attn = take(trows * c.hidden * es);
     p.act = take(trows * c.inter * es);
@@ -451,6 +455,7 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->chain_used = 0;
     s->ao_ctr = (unsigned *)(s->scratch + p.aoctr);
     s->ao_epoch = 0;
+    s->ssq = (float *)(s->scratch + p.ssq);
     SD_HIP_CHECK(hipMemset(s->ao_ctr, 0, 2048));
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
@@ -932,7 +937,7 @@ static bool attn_oproj_ok(const sd_session *s, const RowTab &tab, int s_max) {
 }
 template <typename T>
 static int launch_attn_oproj(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, const void *wo,
-                             hipStream_t st) {
+                             bool resid, hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
     constexpr int D = 128;
     const int s_cap = (int)align_up(s_max, 64);
@@ -949,7 +954,37 @@ static int launch_attn_oproj(sd_session *s, const T *q, const RowTab &tab, int l
     hipLaunchKernelGGL((attn_oproj_kernel<T>), dim3(c.n_heads * tab.n_groups + (c.hidden / 16 + 1) / 2), dim3(512), lds, st, q, tab, layer, out, c.n_heads,
                        c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, (const u32x4 *)wo, s->part, tab.n_rows, c.hidden,
                        q_dim(c), s->ao_ctr, want, g_env.ao_delay, g_env.ao_gap,
-                       g_env.ao_stamps ? (long long *)(s->ao_ctr + 16) : (long long *)nullptr);
+                       g_env.ao_stamps ? (long long *)(s->ao_ctr + 16) : (long long *)nullptr,
+                       (T *)s->x, (T *)s->h, resid ? s->ssq : (float *)nullptr);
+    return SD_OK;
+}
+
+// Norm on load (normload_kernels.h): <= 8 rows of a 16-bit Llama model whose residual rows were left un-normalised (+
+// per-tile sums of squares in s->ssq) by a residual epilogue; the consumer GEMM keeps its whole k-range per workgroup.
+template <typename T>
+static bool norm_on_load_ok(const sd_session *s, const RowTab &tab) {
+    const sd_model_config &c = s->m->cfg;
+    if constexpr (sizeof(T) != 2) return false;
+    if (!g_env.norm_on_load || c.arch != SD_ARCH_LLAMA || !c.fused_layout || s->tp || g_env.chain) return false;
+    // (9..16 rows: the conversions cost more than the launch they replace - +5.7 us on gate/up at 12 rows, tools/gemm_bench.py)
+    return tab.n_rows <= 8 && c.hidden % 1024 == 0 && c.hidden <= 8192;
+}
+template <int EPI, typename H>
+static int launch_gemm_xn(sd_session *s, const void *W, const void *X, int M, int N, int K, const void *norm_w, float eps,
+                          GemmEpiT<H> e, hipStream_t st) {
+    ProfScope ps(s, PC_GEMM, st);
+    SD_REQUIRE(M <= 8 && N % 16 == 0 && K % 1024 == 0 && K <= 8192, "norm-on-load GEMM: M=%d N=%d K=%d", M, N, K);
+    e.nrm_ssq = s->ssq; e.nrm_w = (const H *)norm_w; e.nrm_nt = K / 16; e.nrm_eps = eps;
+    // k-steps whose M valid rows fit one conversion register (C * 4 * M <= 64 lanes)
+    auto go = [&](auto c) {
+        hipLaunchKernelGGL((gemm_bf16_stream_xn<EPI, decltype(c)::value, H>), dim3(N / 16), dim3(256), (size_t)K * sizeof(H), st,
+                           (const u32x4 *)W, (const H *)X, (float *)nullptr, M, N, K, 1, K / 32, e);
+    };
+    using std::integral_constant;
+    if (M <= 4) go(integral_constant<int, 4>{});
+    else if (M == 5) go(integral_constant<int, 3>{});
+    else go(integral_constant<int, 2>{});
+    SD_LAUNCH_CHECK();
     return SD_OK;
 }
 
@@ -1317,11 +1352,13 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                                1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
-        bool o_done = false;
+        bool o_done = false, xn_o = false;
         if constexpr (!std::is_same<T, float>::value) {
             if (attn_oproj_ok<T>(s, tab, s_max)) {
+                // the residual add in the O projection's epilogue, the norm in gate/up's operand load (no launch between)
+                xn_o = pre && fused && norm_on_load_ok<T>(s, tab) && !m->bo[l] && !gemm_plan(gu_cols(c), H, n_new).tiled;
                 ProfScope ps(s, PC_ATTN, st);
-                if ((rc = launch_attn_oproj<T>(s, qb, tab, l, at, s_max, m->wo[l], st)) != SD_OK) return rc;
+                if ((rc = launch_attn_oproj<T>(s, qb, tab, l, at, s_max, m->wo[l], xn_o, st)) != SD_OK) return rc;
                 SD_LAUNCH_CHECK();
                 go.S = 1;
                 go.stride_s = (size_t)16 * H;
@@ -1349,7 +1386,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         if (!o_done && (rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
         const float *osrc = s->part;
         if ((rc = tp_reduce(s, &go, &osrc, n_new, H, st)) != SD_OK) return rc;
-        {
+        if (!xn_o) {
             ProfScope ps(s, PC_NORM, st);
             const int mode = pre ? RES_PRE : RES_POST;
             const T *nw = pre ? (const T *)m->n2w[l] : (const T *)m->n1w[l];
@@ -1359,7 +1396,16 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         // MLP
-        if (fused && !gemm_plan(gu_cols(c), H, n_new).tiled) {
+        if constexpr (!std::is_same<T, float>::value) {
+            if (xn_o) {
+                GemmEpiT<H16> e = {};
+                e.out = (H16 *)ac; e.n_out = I;
+                if ((rc = launch_gemm_xn<EPI_ACT_SILU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, m->n2w[l], c.norm_eps, e, st)) != SD_OK)
+                    return rc;
+            }
+        }
+        if (xn_o) {
+        } else if (fused && !gemm_plan(gu_cols(c), H, n_new).tiled) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)ac; e.bias = (const H16 *)m->bfc1[l]; e.n_out = I;
             rc = llama ? run_gemm_fused<EPI_ACT_SILU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
                                                            float inv_sqrt_d, int s_cap, const u32x4 *__restrict__ Wo,
                                                            float *__restrict__ part, int M, int N, int K,
                                                            unsigned *__restrict__ ctr, unsigned want,
-                                                           int delay_ticks, int gap_ticks, long long *__restrict__ stamps) {
+                                                           int delay_ticks, int gap_ticks, long long *__restrict__ stamps,
+                                                           T *res_x, T *res_h, float *__restrict__ res_ssq) {
+    // res_ssq (or NULL): finish with the residual epilogue (resid_epilogue_step: residual rows updated, un-normalised
+    // operand rows + per-tile sums of squares for the consumer's norm on load) instead of leaving the slab in `part`
     // stamps (or NULL; SD_AO_STAMPS=1, tools/ao_stamps.py): wall_clock64 at the milestones of attention workgroup 0 and of
     // the O workgroups of n-tiles 0 and N/32 - where the launch's time goes
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     // half of the attention workgroups arrive at 9.4-10 us (undisturbed) and the other half at 13-14.7 us, the weights at
     // 8-9 us.  The launch ends at 17.5-19 us against 9.6 + 1.7 + 10.4 for the two launches: 0.15-0.2 ms per verify, not
     // the ~0.35 ms a uniformly undisturbed attention would give.  What delays the second half is the open item.
+    const uint2 xpre = (res_ssq && has_tile) ? resid_prefetch<T>(res_x, M, N, ntg, tid4) : uint2{0u, 0u};
     if (delay_ticks > 0) {
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < delay_ticks) __builtin_amdgcn_s_sleep(8);
@@ -133,6 +137,11 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     ostamp(3);
     __syncthreads();
     GemmEpiT<T> e = {};
-    if (has_tile) gemm_epilogue_step<1, EPI_PART, 1, 1, T>(red, 0, part, M, 16, N, 0, ntg, e, tid4);
+    if (res_ssq) {
+        e.res_x = res_x; e.res_h = res_h; e.res_ssq = res_ssq;
+        if (has_tile) resid_epilogue_step<T>(red, M, N, ntg, e, tid4, xpre);
+    } else if (has_tile) {
+        gemm_epilogue_step<1, EPI_PART, 1, 1, T>(red, 0, part, M, 16, N, 0, ntg, e, tid4);
+    }
     ostamp(4);
 }

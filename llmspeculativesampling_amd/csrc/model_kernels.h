@@ -140,6 +140,16 @@ struct GemmEpiT {
     float *tile_max;
     float *zero_rows;
     long zero_ld;
+    // norm on load (gemm_bf16_stream_xn): X holds the UN-normalised residual rows; nrm_ssq[m][nrm_nt] the per-16-column
+    // sums of their squares (left by the producing epilogue), nrm_w the RMSNorm weight [K]
+    const float *nrm_ssq;
+    const H *nrm_w;
+    int nrm_nt;
+    float nrm_eps;
+    // residual epilogue (resid_epilogue_step): the residual rows [M][N] updated in place, the same rows in the operand
+    // tile layout, and the per-tile sums of squares [M][N/16] for the consumer's norm on load
+    H *res_x, *res_h;
+    float *res_ssq;
     RowTab tab;
 };
 using GemmEpi = GemmEpiT<bf16_t>;
@@ -281,6 +291,42 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
             }
         }
     }
+}
+
+// Residual epilogue of a GEMM whose workgroup holds the COMPLETE sums of one 16-column tile for <= 16 rows (k-split folded
+// inside the workgroup): x' = rnd(x + rnd(sum + bias)) exactly as residual_norm_kernel forms it (modeling_llama.py:440,
+// 446), stored to the residual rows and, un-normalised, to the operand tile layout; plus the tile's sum of squares per
+// row in a fixed order - a lane adds its four columns in sequence, the four quads fold as (q0 + q1) + (q2 + q3) - for the
+// consumer's norm on load (normload_kernels.h).  One wave (tidx < 64); red[wave][0][lane] as in gemm_epilogue_step.
+// resid_prefetch(): the lane's four residual values, to be requested long before the sums are ready.
+template <typename H>
+__device__ __forceinline__ uint2 resid_prefetch(const H *res_x, int M, int N, int nt, int tidx) {
+    const int m = tidx & 15;
+    return (tidx < 64 && m < M) ? *reinterpret_cast<const uint2 *>(res_x + (size_t)m * N + nt * 16 + ((tidx & 63) >> 4) * 4) : uint2{0u, 0u};
+}
+template <typename H, typename E>
+__device__ __forceinline__ void resid_epilogue_step(f32x4 (*red)[1][64], int M, int N, int nt, const E &e, int tidx, uint2 xpre) {
+#pragma clang fp contract(off)
+    if (tidx >= 64) return;
+    const int l = tidx, m = l & 15, col = nt * 16 + (l >> 4) * 4;
+    const f32x4 r = (red[0][0][l] + red[1][0][l]) + (red[2][0][l] + red[3][0][l]);
+    float a2 = 0.f;
+    if (m < M) {
+        H xin[4], v[4];
+        *reinterpret_cast<uint2 *>(xin) = xpre;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y = r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f);
+            const float f = rnd<H>(to_f(xin[c]) + rnd<H>(y));
+            v[c] = (H)f;
+            a2 += f * f;
+        }
+        *reinterpret_cast<uint2 *>(e.res_x + (size_t)m * N + col) = *reinterpret_cast<const uint2 *>(v);
+        *reinterpret_cast<uint2 *>(e.res_h + xoff<H>(m, col, N)) = *reinterpret_cast<const uint2 *>(v);
+    }
+    a2 += __shfl_xor(a2, 16, 64);
+    a2 += __shfl_xor(a2, 32, 64);
+    if (l < 16 && m < M) e.res_ssq[(size_t)m * (N >> 4) + nt] = a2;
 }
 
 template <int MT, int UNROLL, int EPI, int NTW, bool NT_LOADS = true, typename H = bf16_t>

