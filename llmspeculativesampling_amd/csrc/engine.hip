@@ -48,6 +48,8 @@ struct sd_session {
     int chain_used;        // the last forward took the chained launches (its status word is meaningful)
     unsigned *ao_ctr;      // arrival counter of the fused attention + O projection launches (monotonic, fused_kernels.h)
     unsigned ao_epoch;     // arrivals expected so far (wraps; compared as a signed difference)
+    unsigned *fin_ctr;     // [hidden / 16] arrival counters of the k-split GEMM with residual epilogue (monotonic, normload_kernels.h)
+    unsigned fin_epoch;    // arrivals per tile expected so far (wraps; compared as a signed difference)
     float *ssq;            // [16][hidden / 16] per-tile sums of squares left by a residual epilogue (normload_kernels.h)
     size_t spart_floats;
     float *tile_max;    // [SD_MAX_ROWS][vocab / 16] maxima of the head's 16-column tiles (EPI_HEAD)
@@ -146,7 +148,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 1;
+    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -164,7 +166,7 @@ static void refresh_env() {
     g_env.ao_delay = geti("SD_AO_DELAY", 300);        // 10 ns ticks the O workgroups hold their weight requests back (fused_kernels.h)
     g_env.ao_gap = geti("SD_AO_GAP", 100);            // ... and pause after every 8 requests
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
-    g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 1);  // 0: residual+norm stays a launch of its own (A/B runs, compare tests)
+    g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
     if (!g_env.cus) {
         int dev = 0, n = 0;
@@ -355,7 +357,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, h2, cctr, aoctr, ssq, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
+    size_t x, x2, h, h2, cctr, aoctr, ssq, finctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -371,6 +373,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.h2 = take(trows * wide * es);
     p.cctr = take(((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned));
     p.aoctr = take(2048);
+    p.finctr = take((size_t)(c.hidden / 16 + 1) * sizeof(unsigned));      // per-tile arrival counters of gemm_bf16_stream_fin
     p.ssq = take((size_t)16 * (c.hidden / 16 + 1) * sizeof(float));      // per-tile sums of squares of <= 16 rows (norm on load)
     p.q = take((size_t)rows * c.hidden * es);
     p.attn = take(trows * c.hidden * es);
@@ -456,6 +459,9 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->ao_ctr = (unsigned *)(s->scratch + p.aoctr);
     s->ao_epoch = 0;
     s->ssq = (float *)(s->scratch + p.ssq);
+    s->fin_ctr = (unsigned *)(s->scratch + p.finctr);
+    s->fin_epoch = 0;
+    SD_HIP_CHECK(hipMemset(s->fin_ctr, 0, (size_t)(m->cfg.hidden / 16 + 1) * sizeof(unsigned)));
     SD_HIP_CHECK(hipMemset(s->ao_ctr, 0, 2048));
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
@@ -988,6 +994,21 @@ static int launch_gemm_xn(sd_session *s, const void *W, const void *X, int M, in
     return SD_OK;
 }
 
+// The k-split GEMM (streaming kernel's split) finishing with the residual epilogue: rows -> s->x, s->h (un-normalised), s->ssq
+template <typename H>
+static int launch_gemm_fin(sd_session *s, const void *W, const void *X, int M, int N, int K, const void *bias, hipStream_t st) {
+    ProfScope ps(s, PC_GEMM, st);
+    const GemmPlan pl = gemm_plan(N, K, M);
+    SD_REQUIRE(!pl.tiled && M <= 16 && (size_t)pl.S * 16 * N <= s->part_floats, "k-split GEMM with residual epilogue: M=%d N=%d K=%d", M, N, K);
+    GemmEpiT<H> e = {};
+    e.bias = (const H *)bias; e.res_x = (H *)s->x; e.res_h = (H *)s->h; e.res_ssq = s->ssq;
+    s->fin_epoch += (unsigned)(pl.S - 1);
+    hipLaunchKernelGGL((gemm_bf16_stream_fin<H>), dim3((N / 16) * pl.S), dim3(256), 0, st, (const u32x4 *)W, (const H *)X, s->part,
+                       M, N, K, pl.S, pl.ksp, e, s->fin_ctr, s->fin_epoch);
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
 // ---- small-model decode path (small_kernels.h): 5 launches per layer + the head --------------------------------
 static bool small_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
@@ -1330,10 +1351,21 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         if (chain)
             SD_HIP_CHECK(hipMemsetAsync(s->chain_ctr, 0, ((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned), st));
     }
+    bool xn_d = false;                                                // layer l - 1's down projection left un-normalised rows + partials
     for (int l = 0; l < L; ++l) {
         // qkv projection -> rope / scale -> q buffer + in-place KV append (fused into the GEMM's epilogue unless the
         // row count takes the tiled kernel, which leaves slabs for the stand-alone epilogue)
         if ((l == 0 && qkv0_done) || (l > 0 && chain)) {              // (the chained launch of layer l - 1 ran this layer's QKV)
+        } else if (xn_d) {
+            if constexpr (!std::is_same<T, float>::value) {
+                GemmEpiT<H16> e = {};
+                e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
+                e.cos_t = (const H16 *)m->w.rope_cos; e.sin_t = (const H16 *)m->w.rope_sin;
+                e.Hq = c.n_heads; e.Hkv = c.n_kv_heads; e.D = D; e.layer = l; e.tab = tab;
+                e.q_scale = 1.0f / sqrtf((float)D);
+                if ((rc = launch_gemm_xn<EPI_QKV_ROPE, H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, m->n1w[l], c.norm_eps, e, st)) != SD_OK)
+                    return rc;
+            }
         } else if (fused && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
@@ -1418,6 +1450,15 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                                go.stride_s, I, gu_cols(c), c.arch, (const T *)m->bfc1[l], ac, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
+        // down projection: with the norm-on-load seam its last k-slab's workgroups add the residual and the next layer's QKV
+        // normalises on load (no residual+norm launch); the last layer keeps the launch (the final norm feeds the head)
+        xn_d = false;
+        if constexpr (!std::is_same<T, float>::value) {
+            xn_d = g_env.norm_on_load > 1 && pre && fused && l + 1 < L && norm_on_load_ok<T>(s, tab) && !m->bfc2[l] &&
+                   !gemm_plan(qkv_cols(c), H, n_new).tiled && !gemm_plan(H, I, n_new).tiled;
+            if (xn_d && (rc = launch_gemm_fin<H16>(s, m->wdown[l], ac, n_new, H, I, nullptr, st)) != SD_OK) return rc;
+        }
+        if (xn_d) continue;
         if ((rc = run_gemm<H16>(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
         const float *dsrc = s->part;
         if ((rc = tp_reduce(s, &go, &dsrc, n_new, H, st)) != SD_OK) return rc;

@@ -151,3 +151,83 @@ __global__ __launch_bounds__(256, 8) void gemm_bf16_stream_xn(const u32x4 *__res
     __syncthreads();
     gemm_epilogue_step<1, EPI, 1, 1, H>(red, 0, part, M, 16, N, sb, ntg, e);
 }
+
+// ---- the k-split streaming GEMM of <= 16 rows that finishes with the residual epilogue ------------------------------------
+// The down projection (N = hidden: 320 tiles at 13b) needs its k-range cut over SB workgroups per tile to fill the chip
+// evenly - one 16-wave workgroup per tile, whole k-range, was tried: 31 us against 24, the CUs that get two tiles set
+// the time - so no workgroup holds a complete sum.  Here the workgroups of slabs 0 .. SB-2 store their slab write-through
+// (sc1), drain their stores and count in on the tile's counter; the workgroup of the LAST slab - dispatched last, so every
+// other one is resident before it - keeps its sums in registers, waits for the SB - 1 arrivals, reads their slabs (plain
+// loads: nobody has read those lines earlier in this launch), folds in slab order (((s0 + s1) + s2) + s3: the order
+// reduce_part4 uses, so the sums are those of the slab path bit for bit) and runs resid_epilogue_step.  (Giving the
+// last slab a larger share of K so that the others arrive early did not help: 92 / 108 / 116 / 124 % of an equal share
+// all ran equal or slower - the tail is the finisher's own read + epilogue, not the wait.)  The counters are
+// monotonic (the host passes the arrivals expected so far; compared as a signed difference); a wait that exceeds 20 ms
+// poisons the tile with NaN, which the sampler reports - a timed-out launch never returns plausible numbers.
+#define FIN_TIMEOUT_TICKS 2000000ll                           // wall_clock64 runs at 100 MHz
+template <typename H = bf16_t>
+__global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restrict__ Wp, const H *__restrict__ X,
+                                                           float *__restrict__ part, int M, int N, int K, int SB,
+                                                           int ks_per_blk, GemmEpiT<H> e, unsigned *__restrict__ ctr,
+                                                           unsigned want) {
+    constexpr int U = 4;
+    __shared__ f32x4 red[4][1][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int NTG = N >> 4, KS = K >> 5;
+    const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
+    const bool fin = sb == SB - 1;
+    const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
+    const int per = (kb1 - kb0 + 3) >> 2;
+    const int ks0 = min(kb1, kb0 + wv * per), ks1 = min(kb1, ks0 + per), ksa = min(ks0, KS - 1);
+    const uint2 xpre = fin ? resid_prefetch<H>(e.res_x, M, N, ntg, (int)threadIdx.x) : uint2{0u, 0u};
+    const u32x4 *wp = Wp + ((size_t)ntg * KS + ksa) * 64 + lane;
+    const int mrow = (lane & 15) < M ? (lane & 15) : 0;           // rows >= M read row 0 (their output columns are dropped)
+    const H *xp = X + (size_t)ksa * 512 + ((lane >> 4) * 16 + mrow) * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int ks = ks0;
+    for (; ks + U <= ks1; ks += U) {
+        u32x4 w[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const u32x4 *>(xp + u * 512);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16<H>(w[u], x[u], acc);
+        wp += (size_t)U * 64; xp += U * 512;
+    }
+    for (; ks < ks1; ++ks) {
+        acc = mfma16<H>(__builtin_nontemporal_load(wp), *reinterpret_cast<const u32x4 *>(xp), acc);
+        wp += 64; xp += 512;
+    }
+    red[wv][0][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int l = lane, m = l & 15;
+    float *slab = part + (size_t)m * N + ntg * 16 + (l >> 4) * 4;                // + s * 16 * N for slab s
+    const f32x4 own = (red[0][0][l] + red[1][0][l]) + (red[2][0][l] + red[3][0][l]);
+    if (!fin) {
+        if (m < M) store_f32x4<true>(slab + (size_t)sb * 16 * N, own);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slab has left this wave
+        if (l == 0) (void)__hip_atomic_fetch_add(ctr + ntg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    bool timed_out = false;
+    if (SB > 1) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned got = __hip_atomic_load(ctr + ntg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(got - want) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > FIN_TIMEOUT_TICKS) { timed_out = true; break; }
+        }
+    }
+    asm volatile("" ::: "memory");
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 + 1 < SB; ++s2)
+        if (m < M) a += *reinterpret_cast<const f32x4 *>(slab + (size_t)s2 * 16 * N);
+    a += own;
+    if (timed_out) a = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+    red[0][0][l] = a;
+    red[1][0][l] = red[2][0][l] = red[3][0][l] = f32x4{0.f, 0.f, 0.f, 0.f};
+    resid_epilogue_step<H>(red, M, N, ntg, e, l, xpre);
+}
