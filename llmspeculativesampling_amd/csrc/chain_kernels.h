@@ -160,7 +160,7 @@ __device__ __forceinline__ void chain_gemm(const ChainPhase &ph, const ChainArgs
     for (int u = 0; u < CH_PF; ++u) w[u] = u < nk ? __builtin_nontemporal_load(wp + (size_t)u * 64) : u32x4{0u, 0u, 0u, 0u};
 
     if (!(a.flags & 4)) chain_wait(a.ctr, ph.wait_slot, ph.wait_n, a.epoch, a.err, late);
-    const bool poisoned = late && *late;
+    const bool poisoned = late && ph.wait_slot >= 0 && !(a.flags & 4) && *late;      // (no wait: the word was never written)
 
     // operand layout (xoff): tile (0, ks) = 512 elements, lane 16 * quad + m holds X[m][32 ks + 8 quad .. + 8).  Lanes of
     // rows >= M read row 0's fragment (the same 16 bytes as their quad's first lane: no extra traffic, no branch around

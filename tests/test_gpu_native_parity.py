@@ -522,6 +522,7 @@ def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, na
     for flag in ("0", mode):
         os.environ["SD_CHAIN"] = flag
         os.environ["SD_FUSE_ATTN_O"] = "0"                        # the chained launches keep the per-op O projection's k-split
+        os.environ["SD_NORM_ON_LOAD"] = "0"                       # ... and residual_norm_kernel's order of adding up a row's squares
         try:
             ses = m.new_session(160)
             try:
@@ -540,6 +541,7 @@ def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, na
         finally:
             os.environ.pop("SD_CHAIN", None)
             os.environ.pop("SD_FUSE_ATTN_O", None)
+            os.environ.pop("SD_NORM_ON_LOAD", None)
     assert torch.equal(outs[mode][1], outs["0"][1]), "KV rows differ"
     assert torch.equal(outs[mode][0], outs["0"][0]), "logits differ"
 
@@ -1018,8 +1020,8 @@ def test_fused_attention_oproj_launch_vs_two_launches(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["1", "2"], ids=["attention_seam", "both_seams"])
-def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode):
+@pytest.mark.parametrize("mode,shape", [("1", "13b"), ("2", "13b"), ("2", "70b")], ids=["attention_seam", "both_seams", "both_seams_70b_gqa"])
+def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape):
     """normload_kernels.h: for <= 16 rows of a 16-bit Llama model the residual add runs in the epilogue of the GEMM that
     produces the rows and RMSNorm in the operand load of the GEMM that consumes them (per-tile sums of squares handed
     over, summed in a fixed order), against the path with residual_norm_kernel launches (SD_NORM_ON_LOAD=0) at
@@ -1027,9 +1029,14 @@ def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode):
     rnd(w * rnd(x' * r)) - and differ only in the order in which the 5120 squares of a row are added up (r in its last
     bits), so: layer 0's K / V rows are bit-identical (they precede any residual add), the residual-stream-dependent
     logits agree within the bf16 bar of the other forward tests, and ten repetitions are bit-identical (no atomics, no
-    order that depends on scheduling)."""
-    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
-                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, rms_norm_eps=1e-5)
+    order that depends on scheduling).  The 70b shape (hidden 8192, grouped-query attention) takes the MLP -> next-layer
+    seam only (its O projection is too wide for the fused attention launch) and adds its partials up in two passes."""
+    if shape == "13b":
+        cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                          num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, rms_norm_eps=1e-5)
+    else:
+        cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_hidden_layers=3,
+                          num_attention_heads=64, num_key_value_heads=8, max_position_embeddings=512, rms_norm_eps=1e-5)
     m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=400)
     ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(400,))).to(torch.int32).cuda()
     steps = (5, 1, 8, 5, 16, 3)
