@@ -314,22 +314,27 @@ template <int EPI, typename H>
 static int launch_gemm_rows(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, const RowsPlan &pl,
                             const GemmEpiT<H> &e, hipStream_t st) {
     const int MT = Mpad / 16;
-    // activation panel (2 buffers x nwk k-groups x GR_CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x 4 x MT)
-    const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * GR_CH, 4 * pl.nwn);
-    auto go = [&](auto mt_c) {
-        constexpr int MTc = decltype(mt_c)::value;
+    // activation panel (2 buffers x nwk k-groups x CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x 4 x MT);
+    // chunks of 8 k-steps where the panel fits the CU's LDS (one workgroup per CU owns all of it), else 4
+    constexpr size_t lds_cap = 158 * 1024;
+    const int ch = (size_t)1024 * MT * 2 * pl.nwk * 8 <= lds_cap ? 8 : 4;
+    const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * ch, 4 * pl.nwn);
+    SD_REQUIRE(lds <= lds_cap, "gemm_rows: %zu bytes of LDS", lds);
+    auto go = [&](auto mt_c, auto ch_c) {
+        constexpr int MTc = decltype(mt_c)::value, CHc = decltype(ch_c)::value;
         static bool attr = false;                                 // (one flag per instantiation)
         if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H, CHc>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
             attr = true;
         }
-        hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
+        hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H, CHc>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
                            (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e);
     };
-    if (MT == 2) go(std::integral_constant<int, 2>{});
-    else if (MT == 3) go(std::integral_constant<int, 3>{});
-    else if (MT == 4) go(std::integral_constant<int, 4>{});
+    using std::integral_constant;
+    if (MT == 2) { if (ch == 8) go(integral_constant<int, 2>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 2>{}, integral_constant<int, 4>{}); }
+    else if (MT == 3) { if (ch == 8) go(integral_constant<int, 3>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 3>{}, integral_constant<int, 4>{}); }
+    else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); }
     else { sd_set_error("gemm_rows: %d rows", M); return SD_ERR_INVALID; }
     return SD_OK;
 }

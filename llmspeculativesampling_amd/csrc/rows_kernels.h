@@ -11,9 +11,9 @@
 //     Llama-2-13b QKV 960 tiles -> 3 or 4 per CU, gate/up 1728 -> 6 or 7), so SB = 1 fills 256 CUs to 94-98 % and the
 //     QKV / SiLU epilogues stay fused; O / down (320 tiles) take SB = 4 (5 tiles x a quarter of K per CU, exact);
 //   * COMPUTE wave (ni, kg) owns ONE n-tile (t0 + ni) over one of the nwk k-groups of the workgroup's k-range; its
-//     weights go straight to registers (non-temporal, read once) through a 4-slot ring: three chunks of GR_CH k-steps
-//     (12 KiB per wave) are in flight while the fourth is multiplied, and nothing but weight loads sits in its VMEM queue;
-//   * LOADER waves (one per k-group while waves are left, else shared) move the k-group's activation chunk - GR_CH k-steps
+//     weights go straight to registers (non-temporal, read once) in bursts of one chunk - CH k-steps, CH KiB contiguous -
+//     that are multiplied when all of them have landed, and nothing but weight loads sits in its VMEM queue;
+//   * LOADER waves (one per k-group while waves are left, else shared) move the k-group's activation chunk - CH k-steps
 //     x MT tiles, already in MFMA fragment order - from L2 into a double-buffered LDS panel by LDS-DMA
 //     (global_load_lds_dwordx4: no staging registers), one chunk ahead; every compute wave of the k-group reads its
 //     fragments from there, so X traffic per CU is MT KiB per k-step however many tiles the CU owns;
@@ -24,8 +24,6 @@
 #pragma once
 #include "model_kernels.h"
 
-#define GR_CH 4                                               // k-steps per chunk (one barrier per chunk)
-#define GR_RW 4                                               // register slots of the weight ring (3 chunks in flight)
 #define GR_MAX_TILES 7                                        // n-tiles per workgroup = compute waves per k-group
 #define GR_THREADS 1024
 #ifndef GR_PROBE
@@ -40,7 +38,7 @@ __device__ __forceinline__ void gr_glds16(const u32x4 *gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int MT, int EPI, typename H = bf16_t>
+template <int MT, int EPI, typename H = bf16_t, int CH = 8>
 __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
                                                             float *__restrict__ part, int M, int Mpad, int N, int K,
                                                             int NG, int ks_per_blk, int nwn, int nwk, int nld,
@@ -52,7 +50,7 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     constexpr int probe = GR_PROBE;
     extern __shared__ __attribute__((aligned(16))) char gr_smem[];
     // activation panel [2][kg][ck][mt][lane]; after the k-loop the same bytes hold the fold buffer [tile][4][mt][lane]
-    u32x4 (*xs)[GR_CH][MT][64] = reinterpret_cast<u32x4 (*)[GR_CH][MT][64]>(gr_smem);      // xs[buf * nwk + kg]
+    u32x4 (*xs)[CH][MT][64] = reinterpret_cast<u32x4 (*)[CH][MT][64]>(gr_smem);      // xs[buf * nwk + kg]
     f32x4 (*red)[4][MT][64] = reinterpret_cast<f32x4 (*)[4][MT][64]>(gr_smem);
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NT = N >> 4, KS = K >> 5;
@@ -60,7 +58,7 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     const int t0 = (int)((long long)g * NT / NG), t1 = (int)((long long)(g + 1) * NT / NG);
     const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
     const int per = (kb1 - kb0 + nwk - 1) / nwk;                  // k-steps per k-group
-    const int nch = (per + GR_CH - 1) / GR_CH;                    // chunks: the same count for every wave (barriers)
+    const int nch = (per + CH - 1) / CH;                    // chunks: the same count for every wave (barriers)
     const int ncomp = nwn * nwk;
     auto bar = [&]() { if (!(probe & 2)) __syncthreads(); };
 
@@ -81,9 +79,9 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
                 const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)(unsigned)(uintptr_t)&xs[buf * nwk + k2][0][0][0]);               // LDS byte address (wave-uniform)
 #pragma unroll
-                for (int ck = 0; ck < GR_CH; ++ck) {
+                for (int ck = 0; ck < CH; ++ck) {
                     // a k-step past the range re-reads the last valid tile: finite values that meet a zero weight operand
-                    const int ks = min(ks0 + c * GR_CH + ck, ks1 - 1);
+                    const int ks = min(ks0 + c * CH + ck, ks1 - 1);
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
                         gr_glds16(Xp + ((size_t)t * KS + ks) * 64 + lane, base + (unsigned)((ck * MT + t) * 1024));
@@ -102,66 +100,43 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     } else if (comp) {
         // ---------------- compute: tile t0 + ni, k-group kg ----------------
         const int ks0 = min(kb1, kb0 + kg * per), ks1 = min(kb1, ks0 + per);
-        const int nk = ks1 - ks0, dlast = max(nk - 1, 0);
+        const int nk = ks1 - ks0;
         const u32x4 *wp = Wp + ((size_t)(t0 + ni) * KS + min(ks0, KS - 1)) * 64 + lane;
-        // No branch around a load or an MFMA in this loop: a k-step past the wave's range re-loads the last valid tile
-        // and is multiplied as ZERO (selected at use, so the select does not wait for the load at issue time); the panel
-        // tile it meets holds finite values (the loader clamps the same way).  Every operand register is therefore
-        // written on every path.
-        u32x4 wr[GR_RW][GR_CH];
-        const u32x4 zero = {0u, 0u, 0u, 0u};
-        auto issue_w = [&](auto slot_c, int c) {
-            constexpr int slot = decltype(slot_c)::value;
+        // BURSTS, not a ring: a chunk's CH weight tiles (CH KiB, contiguous) are requested together and multiplied when
+        // they have all landed; the other compute waves of the CU cover the wait.  Measured against a 4-slot register
+        // ring that kept three chunks in flight (tools/gemm_bench.py rows, 40 rows): gate/up 51.5 -> 48.3 us, O 16.2 ->
+        // 14.5, QKV 31.4 -> 30.6, down 29.5 -> 29.0 with CH = 8 - the same finding as for the streaming kernel, whose
+        // request-all-then-multiply groups beat every prefetching variant tried.
+        // A k-step past the wave's range is not requested and multiplied as ZERO against the panel tile it meets (which
+        // holds finite values: the loader clamps); every operand register is written on every path.
+        for (int c = 0; c < nch; ++c) {
+            bar();                                                // chunk c's panel is in LDS
+            u32x4 w[CH];
+            if ((c + 1) * CH <= nk) {                             // a whole chunk: CH back-to-back requests, no branch between
 #pragma unroll
-            for (int ck = 0; ck < GR_CH; ++ck) {
-                const int d = min(c * GR_CH + ck, dlast);
-                wr[slot][ck] = (probe & 8) ? zero : __builtin_nontemporal_load(wp + (size_t)d * 64);
-                // keep the loads in program order: the VMEM queue returns in issue order, and hipcc otherwise permutes
-                // independent loads (the first cut's prologue issued chunk 0's tile eleventh of twelve, so its first
-                // wait was vmcnt(1): the whole ring drained)
-                asm volatile("" ::: "memory");
-            }
-        };
-        auto compute = [&](auto slot_c, int c) {
-            constexpr int slot = decltype(slot_c)::value;
-            const int pbuf = (c & 1) * nwk + kg;
+                for (int ck = 0; ck < CH; ++ck)
+                    w[ck] = (probe & 8) ? u32x4{0u, 0u, 0u, 0u} : __builtin_nontemporal_load(wp + (size_t)(c * CH + ck) * 64);
+            } else {
 #pragma unroll
-            for (int ck = 0; ck < GR_CH; ++ck) {
-                const bool valid = c * GR_CH + ck < nk;
-                u32x4 w = wr[slot][ck];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w[q] = valid ? w[q] : 0u;
-                u32x4 xf[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t) xf[t] = (probe & 1) ? zero : xs[pbuf][ck][t][lane];
-                if (!(probe & 4)) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = mfma16<H>(w, xf[t], acc[t]);
-                } else {
-                    acc[0][0] += __uint_as_float((w[0] ^ xf[0][0]) & 1u);       // (keeps the loads alive)
+                for (int ck = 0; ck < CH; ++ck) {
+                    w[ck] = u32x4{0u, 0u, 0u, 0u};
+                    if (c * CH + ck < nk && !(probe & 8)) w[ck] = __builtin_nontemporal_load(wp + (size_t)(c * CH + ck) * 64);
                 }
             }
-        };
-        using std::integral_constant;
-        issue_w(integral_constant<int, 0>{}, 0);
-        issue_w(integral_constant<int, 1>{}, 1);
-        issue_w(integral_constant<int, 2>{}, 2);
-        auto step = [&](auto I_c, int c) {
-            constexpr int I = decltype(I_c)::value;
-            bar();                                                // chunk c's panel is in LDS
-            issue_w(integral_constant<int, (I + 3) % GR_RW>{}, c + 3);
-            compute(integral_constant<int, I>{}, c);
-        };
-        int base = 0;
-        for (; base + GR_RW <= nch; base += GR_RW) {              // (no exit inside a round of the ring: straight-line waits)
-            step(integral_constant<int, 0>{}, base);
-            step(integral_constant<int, 1>{}, base + 1);
-            step(integral_constant<int, 2>{}, base + 2);
-            step(integral_constant<int, 3>{}, base + 3);
+            const int pbuf = (c & 1) * nwk + kg;
+#pragma unroll
+            for (int ck = 0; ck < CH; ++ck) {
+                u32x4 xf[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) xf[t] = (probe & 1) ? u32x4{0u, 0u, 0u, 0u} : xs[pbuf][ck][t][lane];
+                if (!(probe & 4)) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16<H>(w[ck], xf[t], acc[t]);
+                } else {
+                    acc[0][0] += __uint_as_float((w[ck][0] ^ xf[0][0]) & 1u);   // (keeps the loads alive)
+                }
+            }
         }
-        if (base < nch) step(integral_constant<int, 0>{}, base);
-        if (base + 1 < nch) step(integral_constant<int, 1>{}, base + 1);
-        if (base + 2 < nch) step(integral_constant<int, 2>{}, base + 2);
     } else {
         for (int c = 0; c < nch; ++c) bar();                      // idle wave: keeps the barrier count
     }
