@@ -75,7 +75,8 @@ def main():
     write, wrows = load(sys.argv[2])
     gamma, layers, hidden, inter = 4, 40, 5120, 13824
     # calibration: gate/up GEMM dispatches = grid 1728 workgroups * 256 threads
-    is_gu = lambda k, g: re.match(r"gemm_bf16_stream<1, \d+, 1,", k) is not None and g == 1728 * 256
+    # (the norm-on-load form of the same GEMM since round 3: gemm_bf16_stream_xn<EPI = 1, C>)
+    is_gu = lambda k, g: re.match(r"gemm_bf16_stream<1, \d+, 1,|gemm_bf16_stream_xn<1,", k) is not None and g == 1728 * 256
     gu = [v for (_, k, g, v) in frows if is_gu(k, g)]
     gu_bytes = 2 * inter * hidden * 2
     calib = (sum(gu) / len(gu) * 1024 * 2) / gu_bytes if gu else None
@@ -83,7 +84,7 @@ def main():
     # grid 2000 workgroups (N = 32000) and K = 5120 (target): dispatches with grid 2000*256 alternate draft / target;
     # simpler and robust: total over all dispatches of target-sized kernels divided by the number of verify steps.
     n_verify = sum(1 for (_, k, g, v) in frows if is_gu(k, g)) // layers
-    ours = ("gemm_bf16_stream<1", "gemm_small", "attn_kernel", "attn_oproj_kernel", "residual_norm", "norm_probs", "logits_kernel", "embed_kernel",
+    ours = ("gemm_bf16_stream<1", "gemm_bf16_stream_xn", "gemm_bf16_stream_fin", "gemm_small", "attn_kernel", "attn_oproj_kernel", "residual_norm", "norm_probs", "logits_kernel", "embed_kernel",
             "norm_kernel", "sample_kernel", "accept_scan", "qkv_epilogue", "act_kernel")
     tgt_f = sum(v for (_, k, g, v) in frows if any(o in k for o in ours)) * 1024 * 2
     tgt_w = sum(v for (_, k, g, v) in wrows if any(o in k for o in ours)) * 1024
