@@ -505,7 +505,7 @@ def main(argv=None):
         roofline["op_classes_launches_per_verify"] = {k: v[1] // reps for k, v in prof.items()}
         if "gemm" in prof:
             g_ms = prof["gemm"][0] / reps
-            roofline["gemm_kernel"] = {"name": "gemm_bf16_stream<MT=1,UNROLL=4,EPI,NTW=1> (all epilogue variants)", "weight_bytes_per_verify": wbytes,
+            roofline["gemm_kernel"] = {"name": "the weight-streaming GEMM class: gemm_bf16_stream<MT=1,UNROLL=4,EPI,NTW=1> and its norm-on-load / residual-epilogue forms gemm_bf16_stream_xn, gemm_bf16_stream_fin (17-64 rows: gemm_bf16_rows)", "weight_bytes_per_verify": wbytes,
                                        "ms_per_verify": g_ms, "achieved_GBs": wbytes / (g_ms * 1e-3) / 1e9,
                                        "frac": wbytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
