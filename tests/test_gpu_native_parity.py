@@ -1020,8 +1020,10 @@ def test_fused_attention_oproj_launch_vs_two_launches(hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,shape", [("1", "13b"), ("2", "13b"), ("2", "70b")], ids=["attention_seam", "both_seams", "both_seams_70b_gqa"])
-def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape):
+@pytest.mark.parametrize("mode,shape,dtype", [("1", "13b", torch.bfloat16), ("2", "13b", torch.bfloat16), ("2", "70b", torch.bfloat16),
+                                              ("2", "13b", torch.float16)],
+                         ids=["attention_seam", "both_seams", "both_seams_70b_gqa", "both_seams_fp16"])
+def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape, dtype):
     """normload_kernels.h: for <= 16 rows of a 16-bit Llama model the residual add runs in the epilogue of the GEMM that
     produces the rows and RMSNorm in the operand load of the GEMM that consumes them (per-tile sums of squares handed
     over, summed in a fixed order), against the path with residual_norm_kernel launches (SD_NORM_ON_LOAD=0) at
@@ -1037,9 +1039,9 @@ def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape):
     else:
         cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_hidden_layers=3,
                           num_attention_heads=64, num_key_value_heads=8, max_position_embeddings=512, rms_norm_eps=1e-5)
-    m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=400)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=dtype, max_pos=400)
     ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(400,))).to(torch.int32).cuda()
-    steps = (5, 1, 8, 5, 16, 3)
+    steps = (5, 1, 8, 5, 16, 3, 2, 4, 6, 7)
 
     def run():
         ses = m.new_session(400)
@@ -1056,6 +1058,16 @@ def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape):
         os.environ.pop("SD_NORM_ON_LOAD", None)
     os.environ["SD_NORM_ON_LOAD"] = mode
     try:
+        # the path under test really is taken: a 5-row step launches residual_norm_kernel once per layer seam that keeps it
+        ses = m.new_session(400)
+        ses.forward(ids[:200], 0)
+        ses.profile(True)
+        ses.forward(ids[200:205], 5)
+        launches = ses.profile_read()["norm_residual"][1]
+        ses.profile(False)
+        L = cfg.num_hidden_layers
+        kept = {("1", "13b"): L, ("2", "13b"): 1, ("2", "70b"): L + 1}[(mode, shape)]    # (70b: the attention seam keeps its launch)
+        assert launches == kept, (launches, kept)
         first = run()
         assert torch.equal(first[1][0], ref_kv[0])
         assert not bool(torch.isnan(first[0]).any())
