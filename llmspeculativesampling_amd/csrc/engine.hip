@@ -317,7 +317,11 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
     // activation panel (2 buffers x nwk k-groups x CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x 4 x MT);
     // chunks of 8 k-steps where the panel fits the CU's LDS (one workgroup per CU owns all of it), else 4
     constexpr size_t lds_cap = 158 * 1024;
-    const int ch = (size_t)1024 * MT * 2 * pl.nwk * 8 <= lds_cap ? 8 : 4;
+    int ch = 4;
+    for (int c2 : {8, 6})
+        if ((size_t)1024 * MT * 2 * pl.nwk * c2 <= lds_cap) { ch = c2; break; }
+    if (MT == 2) ch = 8;                                          // (2 x 4 x 8 x 2 KiB always fits)
+    if (MT == 3 && ch == 4) ch = 6;                               // (2 x 4 x 6 x 3 KiB = 144 KiB: the widest 3-tile panel)
     const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * ch, 4 * pl.nwn);
     SD_REQUIRE(lds <= lds_cap, "gemm_rows: %zu bytes of LDS", lds);
     auto go = [&](auto mt_c, auto ch_c) {
@@ -332,9 +336,11 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
                            (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e);
     };
     using std::integral_constant;
-    if (MT == 2) { if (ch == 8) go(integral_constant<int, 2>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 2>{}, integral_constant<int, 4>{}); }
-    else if (MT == 3) { if (ch == 8) go(integral_constant<int, 3>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 3>{}, integral_constant<int, 4>{}); }
-    else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); }
+    if (MT == 2) go(integral_constant<int, 2>{}, integral_constant<int, 8>{});
+    else if (MT == 3) { if (ch == 8) go(integral_constant<int, 3>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 3>{}, integral_constant<int, 6>{}); }
+    else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{});
+                        else if (ch == 6) go(integral_constant<int, 4>{}, integral_constant<int, 6>{});
+                        else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); }
     else { sd_set_error("gemm_rows: %d rows", M); return SD_ERR_INVALID; }
     return SD_OK;
 }
