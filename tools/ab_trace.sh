@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B kernel-trace of the verify step: $1 = env assignment for A (e.g. SD_NORM_ON_LOAD=0), B = defaults.  Output gpurun_out/ab/.
+# A/B kernel-trace of the verify step: $1 = env assignment for A (e.g. SD_NORM_ON_LOAD=0), B = defaults; further arguments
+# go to bench.py.  Output gpurun_out/ab/.
 set -o pipefail
 O=gpurun_out/ab; mkdir -p $O
+A=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for tag in A B; do
-  if [ $tag = A ]; then export $1; else unset ${1%%=*}; fi
-  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof$tag -o t -- python3 bench.py --steps 1 --warmup 1 --cpu-baseline 0 --profile-classes 0 --accept-sweep 0 > $O/bench_$tag.log 2>&1 || exit 1
+  if [ $tag = A ]; then export $A; else unset ${A%%=*}; fi
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/prof$tag -o t -- python3 bench.py --steps 1 --warmup 1 --cpu-baseline 0 --profile-classes 0 --accept-sweep 0 "$@" > $O/bench_$tag.log 2>&1 || exit 1
   t=$(find $O/prof$tag -name "*kernel_trace.csv" | head -1)
   python tools/trace_by_grid.py $t > $O/by_grid_$tag.txt 2>&1
   python tools/trace_gaps.py $t > $O/gaps_$tag.txt 2>&1
