@@ -1077,3 +1077,32 @@ def test_norm_on_load_layer_path_vs_residual_norm_launches(hip, mode, shape, dty
             assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
     finally:
         os.environ.pop("SD_NORM_ON_LOAD", None)
+
+
+@pytest.mark.gpu
+def test_norm_on_load_seams_with_rows_of_two_streams(hip):
+    """The norm-on-load seams look at rows, not streams: a shared pass over 3 + 5 = 8 rows of two sequences (positions,
+    KV arenas and attention differ per row through the row table) takes them at the 13b layer shape and must give each
+    stream the logits of its own forward within the bf16 bar, and the same K / V rows in layer 0."""
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
+                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, rms_norm_eps=1e-5)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=12, dtype=torch.bfloat16, max_pos=256)
+    rng = np.random.default_rng(5)
+    lens, new = [60, 33], [3, 5]
+    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(L + n,)).astype(np.int32)).cuda() for L, n in zip(lens, new)]
+    solo = [m.new_session(128) for _ in lens]
+    both = [m.new_session(128) for _ in lens]
+    want = []
+    for a, b, sq, L, n in zip(solo, both, seqs, lens, new):
+        a.forward(sq[:L], 0)
+        b.forward(sq[:L], 0)
+        want.append(a.forward(sq[L:L + n], n).clone())
+    for b in both:
+        b.profile(True)
+    got = hip.engine.batch_forward(both, seqs, new, new).clone()
+    assert both[0].profile_read()["norm_residual"][1] == 1 + cfg.num_hidden_layers     # attention seam (two streams: no fused launch) + the final norm
+    want = torch.cat(want, 0)
+    assert not bool(torch.isnan(got).any())
+    assert float((got - want).abs().max()) <= 0.03 * float(want.abs().max())
+    for a, b, L, n in zip(solo, both, lens, new):
+        assert torch.equal(a.kv[0, :, :, :L + n], b.kv[0, :, :, :L + n])
