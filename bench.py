@@ -473,7 +473,7 @@ def main(argv=None):
     roofline = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "kernel": "verify step (target forward over gamma+1 rows: gemm_bf16_stream chain + attention + epilogues + norm_probs)",
+        "kernel": "verify step (target forward over gamma+1 rows: weight-streaming GEMM chain - gemm_bf16_stream and its norm-on-load / residual-epilogue forms - + attention / fused attention+O + norm_probs)",
         "algorithmic_bytes_per_launch": b_ver, "avg_launch_ms": t_ver, "launches_timed": len(ver_ms),
         "mean_context": S_mean,
         "draft_step_avg_ms": float(np.mean(drf_ms)) if drf_ms else None,
