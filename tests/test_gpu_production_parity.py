@@ -211,8 +211,9 @@ def _perturb_fewbit(sd, seed, frac):
 TOKEN_EXACT_CASES = [("g4_a", 0.08, 4, 5), ("g2", 0.15, 2, 7), ("g4_c", 0.3, 4, 8)]
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["h64", "h1024_seams"])
 @pytest.mark.parametrize("name,frac,gamma,seed", TOKEN_EXACT_CASES, ids=[c[0] for c in TOKEN_EXACT_CASES])
-def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac, gamma, seed):
+def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac, gamma, seed, wide):
     """The bf16 engine (gemm_bf16_stream with the fused QKV / SiLU / head epilogues, the MFMA attention kernel, the
     native loop sd_spec_generate with device Philox) against the oracle's bf16 CPU run fed the same Philox variates,
     token for token, accept length for accept length.  Every fp32 test of this kind goes through gemm_f32_simple; here the
@@ -224,12 +225,18 @@ def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac,
     by exactly one bf16 ulp.  Token-for-token identity over a bf16 trace therefore rests on sampling decisions not sitting
     within an ulp of a tie; of the four traces first written for this test, these three are identical and a fourth (same
     construction, seed 6) parts ways at its sixth token on such a tie - it was removed rather than re-seeded until green,
-    and the statement "bf16 traces are token-exact" is NOT made: the production-shape guarantee is the error rule above."""
+    and the statement "bf16 traces are token-exact" is NOT made: the production-shape guarantee is the error rule above.
+    `wide` runs the same three traces at hidden 1024 / head_dim 128, i.e. through the default path of the 13b target: the
+    fused attention + O launch, gemm_bf16_stream_xn (RMSNorm on load) and gemm_bf16_stream_fin (k-split down projection
+    with the residual epilogue); they are identical to the oracle's as well."""
     V = 512
-    dcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
-                       num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128, rms_norm_eps=1e-5)
-    tcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
-                       num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=128, rms_norm_eps=1e-5)
+    # wide: hidden 1024 with head_dim 128 - the same construction through the fused attention + O launch, the
+    # norm-on-load GEMMs and the k-split down projection with the residual epilogue (the default path of the 13b target)
+    Hd, I, nh, nkv = (1024, 2048, 8, 4) if wide else (64, 128, 2, 1)
+    dcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=Hd, intermediate_size=I, num_hidden_layers=1,
+                       num_attention_heads=nh, num_key_value_heads=nh, max_position_embeddings=128, rms_norm_eps=1e-5)
+    tcfg = ModelConfig(arch="llama", vocab_size=V, hidden_size=Hd, intermediate_size=I, num_hidden_layers=2,
+                       num_attention_heads=nh, num_key_value_heads=nkv, max_position_embeddings=128, rms_norm_eps=1e-5)
     dsd = _fewbit_sparse_sd(dcfg, seed)
     tsd = _fewbit_sparse_sd(tcfg, seed + 100)
     # correlate the pair: the target shares the draft's embedding, first layer (its K / V rows are cut to the single KV
@@ -240,7 +247,7 @@ def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac,
         if k in tsd and tsd[k].shape == v.shape:
             tsd[k] = v
         elif k in tsd and k.endswith(("k_proj.weight", "v_proj.weight")):
-            tsd[k] = v[:hd]
+            tsd[k] = v[:hd * nkv]
     prompt = torch.from_numpy(np.random.default_rng(seed).integers(3, V, size=(1, 9)))
     kw = dict(gamma=gamma, top_k=20, top_p=0.9)
     want, wd = oracle.speculative_sampling(prompt, oracle.RefCausalLM(dcfg, dsd), oracle.RefCausalLM(tcfg, tsd), -1, None, 16,
@@ -248,6 +255,13 @@ def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac,
     dm = hip.engine.SpecDecModel.from_state_dict(dcfg, dsd, dtype=torch.bfloat16)
     tm = hip.engine.SpecDecModel.from_state_dict(tcfg, tsd, dtype=torch.bfloat16)
     assert dm.fused and tm.fused                                  # the fused-epilogue MFMA route, not the fp32 kernels
+    if wide:                                                      # ... and, at hidden 1024, the norm-on-load seams: of the target's
+        ps = tm.new_session(32)                                   # 2 x 2 residual+norm launches only the final norm's is left
+        ps.forward(prompt[0, :4].to(torch.int32).cuda(), 0)
+        ps.profile(True)
+        ps.forward(prompt[0, 4:9].to(torch.int32).cuda(), 5)
+        assert ps.profile_read()["norm_residual"][1] == 1
+        ps.profile(False)
     got, gd = hip.S.speculative_sampling(prompt.cuda(), dm, tm, -1, None, 16, details=True,
                                          rng=hip.noise.DeviceNoise(4242 + seed), **kw)
     print(name, "acc_len oracle", wd["acc_len"], "hip", gd["acc_len"])
