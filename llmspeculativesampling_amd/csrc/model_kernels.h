@@ -391,18 +391,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 #pragma unroll
         for (int t = 0; t < MT; ++t) xp[t] += UNROLL * xstep;
     }
-    for (; ks < ks1; ++ks) {
-        u32x4 w[NTW];
+    if (ks < ks1) {
+        // the last < UNROLL k-steps as ONE burst as well (requested together, multiplied in order): taken one at a time they
+        // cost a memory round trip each - three of a wave's seven at the draft model's K = 768, three on top of six groups
+        // in the 13b down projection
+        const int rem = ks1 - ks;
+        u32x4 w[UNROLL > 1 ? UNROLL - 1 : 1][NTW];
+        u32x4 x[UNROLL > 1 ? UNROLL - 1 : 1][MT];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) { w[j] = __builtin_nontemporal_load(wp[j]); wp[j] += 64; }
+        for (int u = 0; u < UNROLL - 1; ++u)
+            if (u < rem) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const u32x4 x = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t]) : u32x4{0u, 0u, 0u, 0u};
+                for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)u * 64);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                acc[j][t] = mfma16<H>(w[j], x, acc[j][t]);
-            xp[t] += xstep;
-        }
+                for (int t = 0; t < MT; ++t)
+                    x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * xstep) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+        for (int u = 0; u < UNROLL - 1; ++u)
+            if (u < rem) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[j][t] = mfma16<H>(w[u][j], x[u][t], acc[j][t]);
+            }
     }
     // Fold the 4 waves' accumulators through LDS, PT tiles at a time (a fold buffer for all NTW*MT tiles at once would be
     // 64 KiB at 4x4 and cap the kernel at two workgroups per CU), each step followed by its share of the epilogue.

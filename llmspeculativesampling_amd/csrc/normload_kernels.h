@@ -195,9 +195,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restr
         for (int u = 0; u < U; ++u) acc = mfma16<H>(w[u], x[u], acc);
         wp += (size_t)U * 64; xp += U * 512;
     }
-    for (; ks < ks1; ++ks) {
-        acc = mfma16<H>(__builtin_nontemporal_load(wp), *reinterpret_cast<const u32x4 *>(xp), acc);
-        wp += 64; xp += 512;
+    if (ks < ks1) {                                               // the last < 4 k-steps as one burst too
+        const int rem = ks1 - ks;
+        u32x4 w[U - 1], x[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < rem) { w[u] = __builtin_nontemporal_load(wp + (size_t)u * 64); x[u] = *reinterpret_cast<const u32x4 *>(xp + u * 512); }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if (u < rem) acc = mfma16<H>(w[u], x[u], acc);
     }
     red[wv][0][lane] = acc;
     __syncthreads();
