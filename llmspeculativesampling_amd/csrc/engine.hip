@@ -795,6 +795,16 @@ static void launch_gemm_bf16(const void *W, const void *X, float *part, int M, i
                              int ks_per, const GemmEpiT<H> &e, hipStream_t st) {
     const int blocks = (N / 16 / NTW) * S;
     constexpr int UNROLL = NTW >= 8 ? 1 : (MT > 2 ? 2 : 4);        // 4 measured best for decode rows (tools/gemm_bench.py)
+    if constexpr (MT == 1 && NTW == 1) {
+        // a wave's whole k-range in ONE burst when it is 5..8 k-steps (the draft model's K = 768 GEMMs: 6 per wave), instead
+        // of a group of four and a second round trip for the rest
+        const int per_wave = (std::min(ks_per, K / 32) + 3) / 4;
+        if (per_wave > 4 && per_wave <= 8) {
+            hipLaunchKernelGGL((gemm_bf16_stream<1, 8, EPI, 1, true, H>), dim3(blocks), dim3(256), 0, st,
+                               (const u32x4 *)W, (const H *)X, part, M, Mpad, N, K, S, ks_per, e);
+            return;
+        }
+    }
     hipLaunchKernelGGL((gemm_bf16_stream<MT, UNROLL, EPI, NTW, true, H>), dim3(blocks), dim3(256), 0, st,
                        (const u32x4 *)W, (const H *)X, part, M, Mpad, N, K, S, ks_per, e);
 }
