@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SD_ABI_VERSION 3
+#define SD_ABI_VERSION 4
 
 typedef enum {
     SD_OK = 0,
@@ -323,15 +323,23 @@ int sd_session_forward_tree(sd_session *s, const int32_t *tokens, const int32_t 
                             int base_len, float *logits_out, long ld_logits, void *stream);
 int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream);
 
-/* Forwards over <= 16 new rows may run the streaming half of every layer as ONE launch whose phases wait for each other
- * on device-side counters (csrc/chain_kernels.h; same arithmetic as one launch per op).  Every wait is bounded; a wait that
- * ran into its limit leaves a bit in the status word of the LAST forward, read here (blocking copy; 0 = no wait timed out,
- * also when that forward took the launch-per-op path). */
-int sd_session_chain_status(sd_session *s, unsigned *status_out);
-/* Debugging aid: the wall_clock64 (100 MHz) stamps the last fused attention + O-projection launch left when the session
- * was created under SD_AO_STAMPS=1 (fused_kernels.h): [0,1] attention workgroup 0 start / arrival; [2..6] and [8..12] the O
- * workgroups of n-tiles 0 and N/32: start, weights landed, counter seen, MFMAs done, slab stored. */
-int sd_session_ao_stamps(sd_session *s, long long *out144 /* 14 + 2 spare + 64 x (start, arrival) of the heads */);
+/* Single-stream decode / verify forwards of a 16-bit model run two kinds of launches whose workgroups wait for each other
+ * on device-side counters: attention + O projection (csrc/fused_kernels.h) and the k-split down projection with the
+ * residual epilogue (csrc/normload_kernels.h).  Every such wait is bounded (20 ms); one that runs into its limit poisons
+ * its output rows with NaN - the sampler then reports the reference's 'norm logits error' (utils.py:186-188), never
+ * finite numbers - and sets a sticky bit in the session's status word: bit 0 attention + O, bit 1 down projection.
+ * sd_session_fused_status reads and clears the word (blocking copy; the session's stream must be idle); 0 = no wait has
+ * timed out since the last read.  After a non-zero read, and after any forward that returned an error, the next forward
+ * first re-zeroes the counters (stream-ordered), so one failed launch cannot leave every later wait short. */
+int sd_session_fused_status(sd_session *s, unsigned *status_out);
+/* TEST HOOK: the fused launches of the NEXT forward of this session expect `extra` (0..1024) arrivals more than will come,
+ * i.e. every one of their waits times out.  Exists so that the timeout branch is covered by a test (tests/); the forward
+ * after that one is back in step. */
+int sd_session_test_skew_wait(sd_session *s, int extra);
+/* Debugging aid: the per-workgroup records the last fused attention + O-projection launch left when the session was
+ * created under SD_AO_STAMPS=1 (fused_kernels.h, AO_STAMP_WGS): out[w][8] long long for workgroups w < n_wgs <= 512 -
+ * wall_clock64 (100 MHz) at the workgroup's milestones, XCC_ID / HW_ID, and role / head / row group. */
+int sd_session_ao_stamps(sd_session *s, long long *out, int n_wgs);
 
 /* Stream-batched forward: the new rows of up to 16 independent sequences share ONE pass over the
  * weights (same bytes streamed, n_items times the tokens).  Each item names its own session (KV arena), its token
@@ -444,6 +452,7 @@ int sd_session_set_tp(sd_session *s, sd_tp *t);
  * (torch.distributed's store / broadcast, or any side channel).  send / recv are device buffers of this rank's GPU.
  * ------------------------------------------------------------------------------------------ */
 typedef struct sd_comm sd_comm;
+int sd_comm_probe(void);    /* SD_OK when RCCL resolves in this process (dlopen + the five entry points); creates nothing */
 int sd_comm_unique_id(void *id128);
 int sd_comm_init(int rank, int world, const void *id128, sd_comm **out);
 int sd_comm_all_gather_tokens(sd_comm *c, const int32_t *send, int32_t *recv, int rows, int width, void *stream);

@@ -112,8 +112,9 @@ SYMBOLS = [
     ("sd_session_forward", _I, [_VP, _VP, _I, _I, _I, _VP, _L, _VP]),
     ("sd_session_forward_tree", _I, [_VP, _VP, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), _I, _I, _VP, _L, _VP]),
     ("sd_session_compact_kv", _I, [_VP, _I, _VP, _I, _VP]),
-    ("sd_session_chain_status", _I, [_VP, _VP]),
-    ("sd_session_ao_stamps", _I, [_VP, _VP]),
+    ("sd_session_fused_status", _I, [_VP, _VP]),
+    ("sd_session_test_skew_wait", _I, [_VP, _I]),
+    ("sd_session_ao_stamps", _I, [_VP, _VP, _I]),
     ("sd_cand_list_bytes", C.c_size_t, [_I]),
     ("sd_norm_probs_lists", _I, [_VP, _I, _I, _L, _F, _I, _F, _I, _VP, _L, _VP, _VP, _VP, _VP]),
     ("sd_accept_resample", _I, [_VP, _VP, _L, _I, _VP, _I, _I, _VP, _U64, _U64, _U64, _VP, _VP, _I, _I, _VP, _VP]),
@@ -133,6 +134,7 @@ SYMBOLS = [
     ("sd_tp_create_loopback", _I, [_I, C.POINTER(_VP)]),
     ("sd_tp_destroy", _I, [_VP]),
     ("sd_session_set_tp", _I, [_VP, _VP]),
+    ("sd_comm_probe", _I, []),
     ("sd_comm_unique_id", _I, [_VP]),
     ("sd_comm_init", _I, [_I, _I, _VP, C.POINTER(_VP)]),
     ("sd_comm_all_gather_tokens", _I, [_VP, _VP, _VP, _I, _I, _VP]),

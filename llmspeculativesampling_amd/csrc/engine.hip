@@ -11,7 +11,6 @@
 
 #include "model_kernels.h"
 #include "small_kernels.h"
-#include "chain_kernels.h"
 #include "rows_kernels.h"
 #include "fused_kernels.h"
 #include "normload_kernels.h"
@@ -43,11 +42,13 @@ struct sd_session {
     void *x, *h, *qbuf, *attn, *act, *ebuf;
     void *x2;           // second residual-stream buffer of the small-model path (the prologue-fused chain ping-pongs)
     float *spart;       // split-K slabs of the small-model path's O / down GEMMs (its head writes s->part meanwhile)
-    void *h2;           // second normalised-operand buffer and the phase counters (+ error word) of the chained layer
-    unsigned *chain_ctr;   // launch (chain_kernels.h): [CH_MAX_PHASES][CH_CTR_WORDS] + 32 words, zeroed per forward
-    int chain_used;        // the last forward took the chained launches (its status word is meaningful)
+    void *h2;           // second normalised-operand buffer (small-model path)
     unsigned *ao_ctr;      // arrival counter of the fused attention + O projection launches (monotonic, fused_kernels.h)
     unsigned ao_epoch;     // arrivals expected so far (wraps; compared as a signed difference)
+    unsigned *wait_status; // sticky device word: bit 0 a fused attention + O wait timed out, bit 1 a k-split finisher's wait did
+    long long *ao_stamps;  // [AO_STAMP_WGS][8] per-workgroup records of the last stamped fused launch (SD_AO_STAMPS=1)
+    int resync;            // the next forward re-zeroes the arrival counters and epochs first (set after a failed forward)
+    int test_skew, skew_now;   // test hook (sd_session_test_skew_wait): arrivals the NEXT forward's fused waits over-expect
     unsigned *fin_ctr;     // [hidden / 16] arrival counters of the k-split GEMM with residual epilogue (monotonic, normload_kernels.h)
     unsigned fin_epoch;    // arrivals per tile expected so far (wraps; compared as a signed difference)
     float *ssq;            // [16][hidden / 16] per-tile sums of squares left by a residual epilogue (normload_kernels.h)
@@ -146,7 +147,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // Environment tunables, sampled when a session (or a spec handle) is created and by the public one-off GEMM entries - not
 // per launch: a draft step is ~40 getenv() scans otherwise, on the host thread that has to keep the GPU fed.
 struct EnvTun {
-    int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, chain = 0, fuse_embed_qkv = 1, head_tiles = 1;
+    int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
     int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2;
 };
@@ -157,7 +158,6 @@ static void refresh_env() {
     g_env.gemm_units = geti("SD_GEMM_UNITS", -1);
     g_env.small_path = geti("SD_SMALL_PATH", 0);      // off by default: measured slower than the per-op chain
     g_env.small_split_bytes = geti("SD_SMALL_SPLIT_BYTES", 0);
-    g_env.chain = geti("SD_CHAIN", 0);                // 1: in-order chained launch, 2: persistent engine (both measured slower)
     g_env.fuse_embed_qkv = geti("SD_FUSE_EMBED_QKV", 1);
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
     g_env.attn_split_keys = geti("SD_ATTN_SPLIT_KEYS", 384);          // keys per workgroup above which a group's keys are split
@@ -368,7 +368,7 @@ extern "C" size_t sd_session_kv_bytes(const sd_model *m, int max_seq) {
 }
 
 struct ScratchPlan {
-    size_t x, x2, h, h2, cctr, aoctr, ssq, finctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
+    size_t x, x2, h, h2, aoctr, ssq, finctr, q, attn, act, e, apart, part, spart, tmax, tp_in, tp_out, total, part_floats, spart_floats;
 };
 static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     ScratchPlan p;
@@ -382,8 +382,7 @@ static ScratchPlan plan_scratch(const sd_model_config &c, int rows) {
     p.x2 = take((size_t)SMALL_MAX_ROWS * c.hidden * es);
     p.h = take(trows * wide * es);
     p.h2 = take(trows * wide * es);
-    p.cctr = take(((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned));
-    p.aoctr = take(2048);
+    p.aoctr = take(256 + (size_t)AO_STAMP_WGS * 8 * sizeof(long long));   // counter line, status line, stamp records
     p.finctr = take((size_t)(c.hidden / 16 + 1) * sizeof(unsigned));      // per-tile arrival counters of gemm_bf16_stream_fin
     p.ssq = take((size_t)16 * (c.hidden / 16 + 1) * sizeof(float));      // per-tile sums of squares of <= 16 rows (norm on load)
     p.q = take((size_t)rows * c.hidden * es);
@@ -465,15 +464,17 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->last_tile_max = nullptr;
     s->h = s->scratch + p.h;
     s->h2 = s->scratch + p.h2;
-    s->chain_ctr = (unsigned *)(s->scratch + p.cctr);
-    s->chain_used = 0;
     s->ao_ctr = (unsigned *)(s->scratch + p.aoctr);
     s->ao_epoch = 0;
+    s->wait_status = s->ao_ctr + 32;                              // (a 128-byte line of its own)
+    s->ao_stamps = (long long *)(s->ao_ctr + 64);
+    s->resync = 0;
+    s->test_skew = s->skew_now = 0;
     s->ssq = (float *)(s->scratch + p.ssq);
     s->fin_ctr = (unsigned *)(s->scratch + p.finctr);
     s->fin_epoch = 0;
     SD_HIP_CHECK(hipMemset(s->fin_ctr, 0, (size_t)(m->cfg.hidden / 16 + 1) * sizeof(unsigned)));
-    SD_HIP_CHECK(hipMemset(s->ao_ctr, 0, 2048));
+    SD_HIP_CHECK(hipMemset(s->ao_ctr, 0, 256 + (size_t)AO_STAMP_WGS * 8 * sizeof(long long)));
     s->qbuf = s->scratch + p.q;
     s->attn = s->scratch + p.attn;
     s->act = s->scratch + p.act;
@@ -659,6 +660,7 @@ extern "C" int sd_tp_create_rccl(int rank, int world, const void *id128, sd_tp *
 // ---- throughput-mode gather of the sharded streams' token rows: one ncclAllGather over RCCL / xGMI ----
 struct sd_comm { int rank, world; void *comm; };
 
+extern "C" int sd_comm_probe(void) { return rccl_load(); }
 extern "C" int sd_comm_unique_id(void *id128) { return sd_tp_unique_id(id128); }
 
 extern "C" int sd_comm_init(int rank, int world, const void *id128, sd_comm **out) {
@@ -949,40 +951,52 @@ static int launch_attn(sd_session *s, const T *q, const RowTab &tab, int layer, 
 // Attention + O projection in one launch (fused_kernels.h) for <= 8 rows of one stream on a 16-bit model with
 // head_dim 128 and K = n_heads * 128 <= 5120: returns false when the shape does not qualify (the caller then takes the two
 // launches).  On success the O projection's single slab is in s->part.
+#define AO_LDS_MAX (80 * 1024)
+static size_t attn_oproj_lds(int s_max) {
+    constexpr int D = 128;
+    const int s_cap = (int)align_up(s_max, 64);
+    return sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+}
 template <typename T>
 static bool attn_oproj_ok(const sd_session *s, const RowTab &tab, int s_max) {
     const sd_model_config &c = s->m->cfg;
     if constexpr (sizeof(T) != 2) return false;
-    if (!g_env.fuse_attn_o || g_env.chain || s->tp || tab.tree || tab.kv_fp8 || tab.contig) return false;
+    if (!g_env.fuse_attn_o || s->tp || tab.tree || tab.kv_fp8 || tab.contig) return false;
     if (c.head_dim != 128 || tab.n_groups > 2 || tab.n_streams != 1 || tab.n_rows > 16) return false;
     const int K = q_dim(c), N = c.hidden;
     if (K % 128 || K / 128 > AO_NKW || N % 16 || s_max > g_env.attn_split_keys) return false;
     const int cus = g_env.cus > 0 ? g_env.cus : 256;
     if (c.n_heads * tab.n_groups + (N / 16 + 1) / 2 > cus) return false;      // every workgroup resident at once, one per CU
     if ((size_t)16 * N > s->part_floats) return false;
+    // (a context whose score tile does not fit the launch's LDS budget takes the two launches - never an error: the key
+    //  limit SD_ATTN_SPLIT_KEYS is a tuning knob)
+    if (attn_oproj_lds(s_max) > AO_LDS_MAX) return false;
     return true;
 }
 template <typename T>
 static int launch_attn_oproj(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, const void *wo,
                              bool resid, hipStream_t st) {
     const sd_model_config &c = s->m->cfg;
-    constexpr int D = 128;
     const int s_cap = (int)align_up(s_max, 64);
-    const size_t lds = sizeof(float) * ((size_t)ATT_TQ * D + (size_t)(256 / (D / 8)) * ATT_TQ * D + (size_t)ATT_TQ * s_cap);
+    const size_t lds = attn_oproj_lds(s_max);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_oproj_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  80 * 1024);
+                                  AO_LDS_MAX);
         attr = true;
     }
-    SD_REQUIRE(lds <= 80 * 1024, "attn_oproj: %d keys exceed the two-workgroups-per-CU LDS budget", s_max);
-    s->ao_epoch += (unsigned)(c.n_heads * tab.n_groups);         // arrivals counted so far, this launch's included
-    const unsigned want = s->ao_epoch;
+    SD_REQUIRE(lds <= AO_LDS_MAX, "attn_oproj: %d keys exceed the launch's LDS budget", s_max);      // (attn_oproj_ok checked)
+    // arrivals counted so far, this launch's included; the epoch advances only once the launch is known to be enqueued (a
+    // failed launch must not leave every later wait of the session one arrival short)
+    const unsigned n_arrive = (unsigned)(c.n_heads * tab.n_groups);
+    const unsigned want = s->ao_epoch + n_arrive + (unsigned)s->skew_now;
     hipLaunchKernelGGL((attn_oproj_kernel<T>), dim3(c.n_heads * tab.n_groups + (c.hidden / 16 + 1) / 2), dim3(512), lds, st, q, tab, layer, out, c.n_heads,
                        c.n_kv_heads, c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap, (const u32x4 *)wo, s->part, tab.n_rows, c.hidden,
                        q_dim(c), s->ao_ctr, want, g_env.ao_delay, g_env.ao_gap,
-                       g_env.ao_stamps ? (long long *)(s->ao_ctr + 16) : (long long *)nullptr,
-                       (T *)s->x, (T *)s->h, resid ? s->ssq : (float *)nullptr);
+                       g_env.ao_stamps ? s->ao_stamps : (long long *)nullptr,
+                       (T *)s->x, (T *)s->h, resid ? s->ssq : (float *)nullptr, s->wait_status);
+    SD_LAUNCH_CHECK();
+    s->ao_epoch += n_arrive;
     return SD_OK;
 }
 
@@ -992,7 +1006,7 @@ template <typename T>
 static bool norm_on_load_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
     if constexpr (sizeof(T) != 2) return false;
-    if (!g_env.norm_on_load || c.arch != SD_ARCH_LLAMA || !c.fused_layout || s->tp || g_env.chain) return false;
+    if (!g_env.norm_on_load || c.arch != SD_ARCH_LLAMA || !c.fused_layout || s->tp) return false;
     // (9..16 rows: the conversions cost more than the launch they replace - +5.7 us on gate/up at 12 rows, tools/gemm_bench.py)
     return tab.n_rows <= 8 && c.hidden % 1024 == 0 && c.hidden <= 8192;
 }
@@ -1023,10 +1037,11 @@ static int launch_gemm_fin(sd_session *s, const void *W, const void *X, int M, i
     SD_REQUIRE(!pl.tiled && M <= 16 && (size_t)pl.S * 16 * N <= s->part_floats, "k-split GEMM with residual epilogue: M=%d N=%d K=%d", M, N, K);
     GemmEpiT<H> e = {};
     e.bias = (const H *)bias; e.res_x = (H *)s->x; e.res_h = (H *)s->h; e.res_ssq = s->ssq;
-    s->fin_epoch += (unsigned)(pl.S - 1);
+    const unsigned want = s->fin_epoch + (unsigned)(pl.S - 1) + (unsigned)s->skew_now;
     hipLaunchKernelGGL((gemm_bf16_stream_fin<H>), dim3((N / 16) * pl.S), dim3(256), 0, st, (const u32x4 *)W, (const H *)X, s->part,
-                       M, N, K, pl.S, pl.ksp, e, s->fin_ctr, s->fin_epoch);
+                       M, N, K, pl.S, pl.ksp, e, s->fin_ctr, want, s->wait_status);
     SD_LAUNCH_CHECK();
+    s->fin_epoch += (unsigned)(pl.S - 1);                         // (advanced only for a launch that was enqueued)
     return SD_OK;
 }
 
@@ -1178,105 +1193,6 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
 }
 
 
-// ---- chained layer launch (chain_kernels.h): O -> residual+norm -> gate/up -> down -> residual+norm -> next QKV ----------
-// The per-op path's plans (split counts, workgroup shapes) are kept, so both routes give identical bits.
-static bool chain_path_ok(const sd_session *s, const RowTab &tab) {
-    const sd_model_config &c = s->m->cfg;
-    const int enabled = g_env.chain;                                   // 1: in-order chained launch, 2: persistent engine
-    if (!enabled || !is16(c.dtype) || !c.fused_layout || tab.contig || s->tp) return false;
-    if (tab.n_rows > 16 || c.hidden % 32 != 0 || c.hidden < 1024) return false;
-    if (c.arch == SD_ARCH_OPT && (!c.opt_pre_ln || embed_dim(c) != c.hidden)) return false;
-    if (!s->m->w.final_norm_w) return false;
-    const int n = tab.n_rows;
-    const GemmPlan po = gemm_plan(c.hidden, q_dim(c), n), pd = gemm_plan(c.hidden, c.inter, n);
-    if (po.tiled || pd.tiled || gemm_plan(qkv_cols(c), c.hidden, n).tiled || gemm_plan(gu_cols(c), c.hidden, n).tiled) return false;
-    if ((size_t)po.S * 16 * c.hidden > s->part_floats || (size_t)pd.S * 16 * c.hidden > s->spart_floats) return false;
-    if (enabled == 2) {
-        // the engine's loader deals an item's tiles to four consumers in turn: every k-slab must be full-size and a
-        // multiple of 4 k-steps
-        const int shapes[4][3] = {{q_dim(c) / 32, po.ksp, po.S}, {c.inter / 32, pd.ksp, pd.S}, {c.hidden / 32, c.hidden / 32, 1},
-                                  {c.hidden / 32, c.hidden / 32, 1}};
-        for (auto &sh : shapes)
-            if (sh[1] % 4 != 0 || sh[0] != sh[1] * sh[2]) return false;
-    }
-    return true;
-}
-static int chain_mode() { return g_env.chain; }
-
-template <typename H>
-static int launch_chain(sd_session *s, const RowTab &tab, int l, int rn_threads, unsigned epoch, hipStream_t st) {
-    sd_model *m = s->m;
-    const sd_model_config &c = m->cfg;
-    const int Hd = c.hidden, I = c.inter, L = c.n_layers, n = tab.n_rows;
-    const bool llama = c.arch == SD_ARCH_LLAMA;
-    const GemmPlan po = gemm_plan(Hd, q_dim(c), n), pd = gemm_plan(Hd, I, n);
-    ChainArgs<H> a = {};
-    a.M = n; a.hidden = Hd; a.rn_threads = rn_threads; a.eps = c.norm_eps;
-    a.cos_t = (const H *)m->w.rope_cos; a.sin_t = (const H *)m->w.rope_sin;
-    a.Hq = c.n_heads; a.Hkv = c.n_kv_heads; a.D = c.head_dim; a.q_scale = 1.0f / sqrtf((float)c.head_dim);
-    a.ctr = s->chain_ctr; a.err = s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS; a.epoch = epoch;
-    static const unsigned dbg_flags = getenv("SD_CHAIN_FLAGS") ? (unsigned)atoi(getenv("SD_CHAIN_FLAGS")) : 0u;
-    a.flags = dbg_flags;
-    a.tab = tab;
-    int blk = 0, np = 0;
-    auto add = [&](ChainPhase ph) {
-        ph.blk0 = blk;
-        ph.wait_slot = np ? np - 1 : -1;
-        ph.wait_n = np ? a.ph[np - 1].nblk : 0;
-        ph.sig_slot = np;
-        blk += ph.nblk;
-        a.ph[np++] = ph;
-    };
-    auto gemm = [&](int epi, const void *W, const void *X, float *part, int N, int K, int S, int ksp, void *out,
-                    const void *bias, int n_out, int layer) {
-        ChainPhase ph = {};
-        ph.type = CH_GEMM; ph.epi = epi; ph.nblk = (N / 16) * S;
-        ph.W = (const u32x4 *)W; ph.X = X; ph.part = part; ph.N = N; ph.K = K; ph.SB = S; ph.ks_per_blk = ksp;
-        ph.out = out; ph.bias = bias; ph.n_out = n_out; ph.layer = layer;
-        add(ph);
-    };
-    auto rn = [&](const float *slab, int S, const void *bias, const void *nw, const void *nb, int mode, void *hout) {
-        ChainPhase ph = {};
-        ph.type = CH_RN; ph.nblk = n;
-        ph.xres = s->x; ph.slab = slab; ph.S = S; ph.stride_s = (size_t)16 * Hd; ph.bias = bias; ph.nw = nw; ph.nb = nb;
-        ph.mode = mode; ph.out = hout;
-        add(ph);
-    };
-    gemm(EPI_PART, m->wo[l], s->attn, s->part, Hd, q_dim(c), po.S, po.ksp, nullptr, nullptr, 0, l);
-    rn(s->part, po.S, m->bo[l], m->n2w[l], m->n2b[l], RES_PRE, s->h2);
-    gemm(llama ? EPI_ACT_SILU : EPI_ACT_RELU, m->wgu[l], s->h2, nullptr, gu_cols(c), Hd, 1, Hd / 32, s->act, m->bfc1[l], I, l);
-    gemm(EPI_PART, m->wdown[l], s->act, s->spart, Hd, I, pd.S, pd.ksp, nullptr, nullptr, 0, l);
-    if (l + 1 < L) {
-        rn(s->spart, pd.S, m->bfc2[l], m->n1w[l + 1], m->n1b[l + 1], RES_PRE, s->h);
-        gemm(llama ? EPI_QKV_ROPE : EPI_QKV_PLAIN, m->wqkv[l + 1], s->h, nullptr, qkv_cols(c), Hd, 1, Hd / 32, s->qbuf,
-             m->bqkv[l + 1], 0, l + 1);
-    } else {
-        rn(s->spart, pd.S, m->bfc2[l], m->w.final_norm_w, m->w.final_norm_b, RES_PRE, s->h);
-    }
-    a.ph[np - 1].sig_slot = -1;                                        // the launch boundary publishes the last phase
-    a.n_phases = np;
-    ProfScope ps(s, PC_GEMM, st);
-    if (chain_mode() == 2) {
-        // one engine workgroup per CU (its LDS ring leaves no room for a second one), all resident at once
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            SD_HIP_CHECK(hipGetDevice(&dev));
-            SD_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(engine_kernel<H, SD_ARCH_LLAMA>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EngShared)));
-            SD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(engine_kernel<H, SD_ARCH_OPT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(EngShared)));
-        }
-        SD_REQUIRE(cus >= n, "engine: fewer CUs than rows");
-        if (llama) hipLaunchKernelGGL((engine_kernel<H, SD_ARCH_LLAMA>), dim3(cus), dim3(EN_THREADS), sizeof(EngShared), st, a);
-        else hipLaunchKernelGGL((engine_kernel<H, SD_ARCH_OPT>), dim3(cus), dim3(EN_THREADS), sizeof(EngShared), st, a);
-    } else if (llama) hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_LLAMA>), dim3(blk), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((chain_kernel<H, SD_ARCH_OPT>), dim3(blk), dim3(256), 0, st, a);
-    SD_LAUNCH_CHECK();
-    return SD_OK;
-}
-
 template <typename T>
 static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits,
                         hipStream_t st) {
@@ -1364,19 +1280,11 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         }
     }
 
-    bool chain = false;
-    s->chain_used = 0;
-    if constexpr (!std::is_same<T, float>::value) {
-        chain = chain_path_ok(s, tab);
-        s->chain_used = chain ? 1 : 0;
-        if (chain)
-            SD_HIP_CHECK(hipMemsetAsync(s->chain_ctr, 0, ((size_t)CH_MAX_PHASES * CH_CTR_WORDS + 32) * sizeof(unsigned), st));
-    }
     bool xn_d = false;                                                // layer l - 1's down projection left un-normalised rows + partials
     for (int l = 0; l < L; ++l) {
         // qkv projection -> rope / scale -> q buffer + in-place KV append (fused into the GEMM's epilogue unless the
         // row count takes the tiled kernel, which leaves slabs for the stand-alone epilogue)
-        if ((l == 0 && qkv0_done) || (l > 0 && chain)) {              // (the chained launch of layer l - 1 ran this layer's QKV)
+        if (l == 0 && qkv0_done) {
         } else if (xn_d) {
             if constexpr (!std::is_same<T, float>::value) {
                 GemmEpiT<H16> e = {};
@@ -1428,12 +1336,6 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             }
             if (rc != SD_OK) return rc;
             SD_LAUNCH_CHECK();
-        }
-        if constexpr (!std::is_same<T, float>::value) {
-            if (chain) {
-                if ((rc = launch_chain<T>(s, tab, l, rn_threads, (unsigned)(l + 1), st)) != SD_OK) return rc;
-                continue;
-            }
         }
         // output projection + residual (+ norm feeding the MLP)
         if (!o_done && (rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
@@ -1595,27 +1497,25 @@ static int launch_attn_bf16(sd_session *s, const bf16_t *q, const RowTab &tab, i
 
 static int run_forward(sd_session *s, const RowTab &tab, int s_max, float *logits_out, long ld_logits, void *stream) {
     int rc;
+    if (s->resync) {
+        // the previous forward of this session failed part-way (or ran with a test skew): its fused launches' arrival counters
+        // and the host's epochs may disagree, and every later wait would then run into its 20 ms limit.  Stream-ordered
+        // re-zeroing behind whatever of that forward did run puts both back in step.
+        SD_HIP_CHECK(hipMemsetAsync(s->fin_ctr, 0, (size_t)(s->m->cfg.hidden / 16 + 1) * sizeof(unsigned), (hipStream_t)stream));
+        SD_HIP_CHECK(hipMemsetAsync(s->ao_ctr, 0, 128, (hipStream_t)stream));
+        s->ao_epoch = s->fin_epoch = 0;
+        s->resync = 0;
+    }
+    s->skew_now = s->test_skew;
+    s->test_skew = 0;
     if (s->m->cfg.dtype == SD_BF16)
         rc = forward_impl<bf16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
     else if (s->m->cfg.dtype == SD_F16)
         rc = forward_impl<f16_t>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
     else
         rc = forward_impl<float>(s, tab, s_max, logits_out, ld_logits, (hipStream_t)stream);
-    if (rc == SD_OK && s->chain_used) {
-        // The chained launches (SD_CHAIN=1|2, experimental, off by default) bound every device-side wait; a wait that ran
-        // into its limit carried on with stale operands and left a bit in the status word.  Such a forward must not hand
-        // its logits back: the status is read here (one stream sync, acceptable for an experimental mode) and a non-zero
-        // word fails the call.
-        unsigned status = 0;
-        SD_HIP_CHECK(hipMemcpyAsync(&status, s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS, sizeof(unsigned),
-                                    hipMemcpyDeviceToHost, (hipStream_t)stream));
-        SD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-        if (status != 0) {
-            sd_set_error("chained layer launch (SD_CHAIN=%d): a phase wait hit its time limit (status %#x); the forward's "
-                         "results are invalid - rerun with SD_CHAIN=0", g_env.chain, status);
-            return SD_ERR_HIP;
-        }
-    }
+    if (rc != SD_OK || s->skew_now) s->resync = 1;
+    s->skew_now = 0;
     return rc;
 }
 
@@ -1704,18 +1604,34 @@ __global__ void kv_compact_kernel(char *kv, int max_seq, int row_bytes, int base
     }
 }
 
-// debugging aid (tools/ao_stamps.py): the 14 wall_clock64 stamps the last fused attention + O launch left (SD_AO_STAMPS=1)
-extern "C" int sd_session_ao_stamps(sd_session *s, long long *out14) {
-    SD_REQUIRE(s && out14, "sd_session_ao_stamps: null argument");
-    SD_HIP_CHECK(hipMemcpy(out14, s->ao_ctr + 16, (14 + 2 + 128) * sizeof(long long), hipMemcpyDeviceToHost));
+// debugging aid (tools/ao_stamps.py): the per-workgroup records the last fused attention + O launch left (SD_AO_STAMPS=1):
+// out[w][8] for workgroup w < n_wgs <= AO_STAMP_WGS - see AO_ST_* in fused_kernels.h
+extern "C" int sd_session_ao_stamps(sd_session *s, long long *out, int n_wgs) {
+    SD_REQUIRE(s && out && n_wgs >= 1 && n_wgs <= AO_STAMP_WGS, "sd_session_ao_stamps: 1..%d workgroup records", AO_STAMP_WGS);
+    SD_HIP_CHECK(hipMemcpy(out, s->ao_stamps, (size_t)n_wgs * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return SD_OK;
 }
 
-extern "C" int sd_session_chain_status(sd_session *s, unsigned *status_out) {
-    SD_REQUIRE(s && status_out, "sd_session_chain_status: null argument");
-    *status_out = 0;
-    if (!s->chain_used) return SD_OK;
-    SD_HIP_CHECK(hipMemcpy(status_out, s->chain_ctr + (size_t)CH_MAX_PHASES * CH_CTR_WORDS, sizeof(unsigned), hipMemcpyDeviceToHost));
+// Sticky status of the in-launch waits of this session's fused launches (attention + O projection: bit 0; k-split GEMM with
+// the residual epilogue: bit 1).  A wait that ran into its 20 ms limit poisons its output with NaN - the sampler then
+// reports 'norm logits error' - and sets its bit here, so the host can tell a timed-out hand-off from a model that
+// produced NaN.  Reads and clears the word; call with the session's stream idle.
+extern "C" int sd_session_fused_status(sd_session *s, unsigned *status_out) {
+    SD_REQUIRE(s && status_out, "sd_session_fused_status: null argument");
+    SD_HIP_CHECK(hipMemcpy(status_out, s->wait_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (*status_out) {
+        SD_HIP_CHECK(hipMemset(s->wait_status, 0, sizeof(unsigned)));
+        s->resync = 1;                                            // the counters may be short of the epochs now
+    }
+    return SD_OK;
+}
+
+// TEST HOOK: the fused launches of the NEXT forward of this session expect `extra` more arrivals than will come, so their
+// waits run into the time limit (tests/: the timeout branch must surface as NaN logits / 'norm logits error' and a status
+// bit, never as finite numbers).  The forward after that re-synchronises counters and epochs.
+extern "C" int sd_session_test_skew_wait(sd_session *s, int extra) {
+    SD_REQUIRE(s && extra >= 0 && extra <= 1024, "sd_session_test_skew_wait: extra in 0..1024");
+    s->test_skew = extra;
     return SD_OK;
 }
 
@@ -2137,6 +2053,12 @@ extern "C" int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int
             bool samp = false;
             for (int i = g; i < 2 * g; ++i) samp = samp || ew[i] != 0;
             *err_out = samp ? 1 : 2;
+            // a NaN row may be the poison of a timed-out in-launch wait (fused_kernels.h / normload_kernels.h): say so
+            unsigned wd = 0, wt = 0;
+            if (hipMemcpy(&wd, sp->draft->wait_status, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(&wt, sp->target->wait_status, sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess && (wd | wt))
+                sd_set_error("sd_spec_generate: a fused launch's in-launch wait timed out (status draft %#x, target %#x; "
+                             "sd_session_fused_status): its rows were poisoned with NaN", wd, wt);
             break;
         }
         if (sp->timing && (draft_ms_out || target_ms_out)) {

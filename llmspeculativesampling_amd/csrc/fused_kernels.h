@@ -14,7 +14,7 @@
 // sharing it (the first cut: 256-thread workgroups, two per CU) made the last attention workgroup arrive at 16-17 us
 // instead of ~8 and the launch no faster than two (tools/ao_stamps.py).
 //
-// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"; the form chain_kernels.h uses): the attention rows are
+// Hand-off (MI355X_MICROARCH.md, "inter-workgroup visibility"): the attention rows are
 // stored write-through (sc1, 8-byte stores), every storing wave drains its stores (s_waitcnt vmcnt(0)), a workgroup
 // barrier, then ONE lane adds to the counter (agent scope).  The consumer's first wave polls the counter with agent-scope
 // relaxed loads, the other waves join it at a workgroup barrier, and only then is the first load of the rows issued - a
@@ -31,6 +31,15 @@
 #define AO_NKW 40                                             // k-steps a wave keeps in registers (K <= 4 * 32 * AO_NKW = 5120)
 #define AO_XPF 8                                              // activation fragments requested ahead
 #define AO_TIMEOUT_TICKS 2000000ll                            // wall_clock64 runs at 100 MHz: 20 ms
+// Stamped runs (SD_AO_STAMPS=1, tools/ao_stamps.py): EVERY workgroup w < AO_STAMP_WGS leaves a record of 8 words at
+// stamps + 8 w - wall_clock64 (10 ns ticks) at its milestones plus where it ran - so that "which attention workgroups are
+// late" can be tied to a head, an XCD, a shader engine or a CU:
+//   attention workgroup: [0] start, [1] scores done (K tiles landed, QK^T, LDS writes), [2] softmax done, [3] P.V done (V
+//                        landed), [4] output stores issued, [5] stores acknowledged + arrival counted
+//   O workgroup:         [0] start, [1] own weights landed, [2] counter seen, [3] MFMAs done, [4] epilogue stored, [5] 0
+//   both:                [6] XCC_ID | HW_ID << 8 (HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13),
+//                        [7] role << 32 | head or first n-tile << 8 | row group
+#define AO_STAMP_WGS 512
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict__ qbuf, RowTab tab, int layer,
@@ -39,27 +48,33 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
                                                            float *__restrict__ part, int M, int N, int K,
                                                            unsigned *__restrict__ ctr, unsigned want,
                                                            int delay_ticks, int gap_ticks, long long *__restrict__ stamps,
-                                                           T *res_x, T *res_h, float *__restrict__ res_ssq) {
+                                                           T *res_x, T *res_h, float *__restrict__ res_ssq,
+                                                           unsigned *__restrict__ wait_status) {
     // res_ssq (or NULL): finish with the residual epilogue (resid_epilogue_step: residual rows updated, un-normalised
     // operand rows + per-tile sums of squares for the consumer's norm on load) instead of leaving the slab in `part`
-    // stamps (or NULL; SD_AO_STAMPS=1, tools/ao_stamps.py): wall_clock64 at the milestones of attention workgroup 0 and of
-    // the O workgroups of n-tiles 0 and N/32 - where the launch's time goes
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    auto stamp = [&](int slot) { if (stamps && threadIdx.x == 0) stamps[slot] = wall_clock64(); };
+    long long *my_st = (stamps && (int)blockIdx.x < AO_STAMP_WGS) ? stamps + 8 * (size_t)blockIdx.x : nullptr;
+    auto stamp = [&](int slot) { if (my_st && threadIdx.x == 0) my_st[slot] = wall_clock64(); };
     const int n_att = Hq * tab.n_groups;                          // attention workgroups: (head, row group), head fastest
+    if (my_st && threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        const bool att = (int)blockIdx.x < n_att;
+        my_st[6] = (long long)((xcc & 0xffu) | ((unsigned long long)hw << 8));
+        my_st[7] = ((long long)(att ? 0 : 1) << 32) |
+                   ((long long)(att ? (int)blockIdx.x % Hq : 2 * ((int)blockIdx.x - n_att)) << 8) | (att ? (int)blockIdx.x / Hq : 0);
+        my_st[5] = 0;
+    }
+    stamp(0);
     if ((int)blockIdx.x < n_att) {
         if (threadIdx.x >= 256) return;                           // (an ended wave is not counted by the barriers below)
-        if (blockIdx.x == 0) stamp(0);
-        // (stamped runs: every head's time when its stores are ISSUED, then when they are acknowledged and counted)
         // ---- attention of head blockIdx.x (one row group, whole key range), rows stored write-through ----
         attn_body<T, 128, false, false, true>(qbuf, tab, layer, attn_out, Hq, Hkv, arch, inv_sqrt_d, s_cap, 1, nullptr,
-                                              (int)blockIdx.x % Hq, (int)blockIdx.x / Hq, 0, smem);
-        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x);
+                                              (int)blockIdx.x % Hq, (int)blockIdx.x / Hq, 0, smem, my_st);
+        stamp(4);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's stores have left
         __syncthreads();
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x == 0) stamp(1);
-        if (stamps && blockIdx.x < 64) stamp(16 + 2 * (int)blockIdx.x + 1);       // every head's arrival ...
+        stamp(5);
         return;
     }
     // ---- O projection of n-tiles 2 b and 2 b + 1 (b = blockIdx.x - Hq): 4 waves x a quarter of K each, weights first ----
@@ -69,9 +84,7 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     const int KS = K >> 5, ntg_raw = 2 * ((int)blockIdx.x - n_att) + half;
     const bool has_tile = ntg_raw < (N >> 4);
     const int ntg = has_tile ? ntg_raw : 0;
-    const int sbase = ntg_raw == 0 ? 2 : (ntg_raw == (N >> 5) ? 8 : -1);  // stamp slots of the two observed O tiles
-    auto ostamp = [&](int i) { if (sbase >= 0 && stamps && tid4 == 0) stamps[sbase + i] = wall_clock64(); };
-    ostamp(0);
+    auto ostamp = [&](int i) { stamp(i); };                      // (thread 0 = first thread of the first n-tile's half)
     const int per = (KS + 3) >> 2;                                // gemm_bf16_stream's quarters (SB = 1)
     const int ks0 = min(KS, wv * per), ks1 = min(KS, ks0 + per), nk = ks1 - ks0, dlast = max(nk - 1, 0);
     const u32x4 *wp = Wo + ((size_t)ntg * KS + min(ks0, KS - 1)) * 64 + lane;
@@ -132,7 +145,10 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
         acc = mfma16<T>(wu, x[u % AO_XPF], acc);                  // k-steps in order: the streaming kernel's sum
         if (u + AO_XPF < AO_NKW) x[u % AO_XPF] = ldx(u + AO_XPF);
     }
-    if (__builtin_amdgcn_readfirstlane((int)timed_out)) acc = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+    if (__builtin_amdgcn_readfirstlane((int)timed_out)) {
+        acc = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+        if (threadIdx.x == 0) (void)__hip_atomic_fetch_or(wait_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     red[wv][0][lane] = acc;
     ostamp(3);
     __syncthreads();

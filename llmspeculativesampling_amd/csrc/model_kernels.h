@@ -160,7 +160,7 @@ __device__ __forceinline__ void store4(H *dst, float a, float b, float c, float 
     *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
-// Write-through (sc1) stores for data another workgroup of the SAME launch reads (chain_kernels.h): a relaxed agent-scope
+// Write-through (sc1) stores for data another workgroup of the SAME launch reads (fused_kernels.h, normload_kernels.h): a relaxed agent-scope
 // atomic store is a plain global_store with the sc1 bit, so the bytes are in memory (not in this XCD's L2 only) once the
 // wave's vmcnt drains; pointers are 8-byte aligned at every call site.
 __device__ __forceinline__ void store8_wt(void *dst, uint2 v) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ void store4_maybe_wt(H *dst, float a, float b, float 
 // One fold step of the streaming GEMMs' epilogue: red[wave][pp][lane] holds the 4 waves' accumulators of PT tiles; the
 // folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
 // gemm_small (small_kernels.h).
-// E: GemmEpiT<H>, or any view with the same member names (chain_kernels.h passes one whose `tab` is a reference).
+// E: GemmEpiT<H>, or any view with the same member names.
 template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false>
 __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
                                                    int N, int sb, int ntg, const E &e, int tid_ = -1) {
@@ -644,7 +644,7 @@ template <typename T>
 __device__ __forceinline__ void norm_row(const float *__restrict__ xs, int H, const T *__restrict__ w,
                                          const T *__restrict__ b, float eps, int kind, float *red,
                                          T *__restrict__ hbase, int row) {
-    // (no fused multiply-adds here: the same statistics are computed by other kernels - small_kernels.h, chain_kernels.h -
+    // (no fused multiply-adds here: the same statistics are computed by other kernels - small_kernels.h -
     // that must give the same bits, and what the compiler contracts depends on the code around an expression)
 #pragma clang fp contract(off)
     float a = 0.f, a2 = 0.f;
@@ -972,7 +972,10 @@ __device__ long long g_att_stamps[16];
 template <typename T, int D, bool KV8, bool TREE, bool WT>
 __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowTab &tab, int layer, T *__restrict__ out, int Hq,
                                           int Hkv, int arch, float inv_sqrt_d, int s_cap, int nsplit,
-                                          float *__restrict__ partial, int head, int bg, int bz, char *smem) {
+                                          float *__restrict__ partial, int head, int bg, int bz, char *smem,
+                                          long long *wg_stamps = nullptr) {
+    // wg_stamps (or NULL): this workgroup's record of a stamped fused launch (fused_kernels.h, AO_STAMP_WGS): slots 1..3
+    auto wstamp = [&](int slot) { if (wg_stamps && threadIdx.x == 0) wg_stamps[slot] = wall_clock64(); };
     static_assert(!KV8 || (sizeof(T) == 2 && D >= 32), "fp8 KV needs a 16-bit model type and the MFMA score path");
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     constexpr int ATT_RG = 256 / (D / 8);                         // key groups of the P.V phase, each leaves a partial sum
@@ -1131,6 +1134,7 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
         }
     }
     ATT_STAMP(1);
+    wstamp(1);
     __syncthreads();
     ATT_STAMP(2);
 
@@ -1234,6 +1238,7 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
         }
     }
     ATT_STAMP(3);
+    wstamp(2);
     __syncthreads();
     ATT_STAMP(4);
 
@@ -1295,6 +1300,7 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
         else pv(std::integral_constant<int, ATT_TQ>{});
     }
     ATT_STAMP(5);
+    wstamp(3);
     __syncthreads();
     ATT_STAMP(6);
     if (nsplit > 1) {

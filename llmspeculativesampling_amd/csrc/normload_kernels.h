@@ -157,19 +157,31 @@ __global__ __launch_bounds__(256, 8) void gemm_bf16_stream_xn(const u32x4 *__res
 // evenly - one 16-wave workgroup per tile, whole k-range, was tried: 31 us against 24, the CUs that get two tiles set
 // the time - so no workgroup holds a complete sum.  Here the workgroups of slabs 0 .. SB-2 store their slab write-through
 // (sc1), drain their stores and count in on the tile's counter; the workgroup of the LAST slab - dispatched last, so every
-// other one is resident before it - keeps its sums in registers, waits for the SB - 1 arrivals, reads their slabs (plain
-// loads: nobody has read those lines earlier in this launch), folds in slab order (((s0 + s1) + s2) + s3: the order
-// reduce_part4 uses, so the sums are those of the slab path bit for bit) and runs resid_epilogue_step.  (Giving the
+// other one is resident before it - keeps its sums in registers, waits for the SB - 1 arrivals, reads their slabs, folds in
+// slab order (((s0 + s1) + s2) + s3: the order reduce_part4 uses, so the sums are those of the slab path bit for bit) and
+// runs resid_epilogue_step.  The slabs of this kernel are TILE-MAJOR - [slab][n-tile][16 rows][16 columns], 1 KiB per
+// (slab, tile), every 128-byte line of it written whole by one wave of one workgroup and read by one finisher - so that no
+// finisher can pull in a line that still waits for another tile's producer (row-major slabs put tiles 2j and 2j + 1 on
+// one line), and the finisher reads them with sc1 loads after its poll has matched: the write-through hand-off of
+// MI355X_MICROARCH.md ("inter-workgroup visibility", first row of the sc1 table) in every cell.  (Giving the
 // last slab a larger share of K so that the others arrive early did not help: 92 / 108 / 116 / 124 % of an equal share
 // all ran equal or slower - the tail is the finisher's own read + epilogue, not the wait.)  The counters are
 // monotonic (the host passes the arrivals expected so far; compared as a signed difference); a wait that exceeds 20 ms
 // poisons the tile with NaN, which the sampler reports - a timed-out launch never returns plausible numbers.
 #define FIN_TIMEOUT_TICKS 2000000ll                           // wall_clock64 runs at 100 MHz
+// 16 bytes another workgroup of this launch stored write-through: two 8-byte sc1 loads (relaxed agent-scope atomics lower
+// to global_load_dwordx2 sc1 - L1 bypassed, served by L2 / memory)
+__device__ __forceinline__ f32x4 load_f32x4_sc1(const float *p) {
+    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                 __uint_as_float((unsigned)(b >> 32))};
+}
 template <typename H = bf16_t>
 __global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restrict__ Wp, const H *__restrict__ X,
                                                            float *__restrict__ part, int M, int N, int K, int SB,
                                                            int ks_per_blk, GemmEpiT<H> e, unsigned *__restrict__ ctr,
-                                                           unsigned want) {
+                                                           unsigned want, unsigned *__restrict__ wait_status) {
     constexpr int U = 4;
     __shared__ f32x4 red[4][1][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restr
     __syncthreads();
     if (threadIdx.x >= 64) return;
     const int l = lane, m = l & 15;
-    float *slab = part + (size_t)m * N + ntg * 16 + (l >> 4) * 4;                // + s * 16 * N for slab s
+    float *slab = part + ((size_t)ntg * 16 + m) * 16 + (l >> 4) * 4;             // + s * 16 * N for slab s (tile-major)
     const f32x4 own = (red[0][0][l] + red[1][0][l]) + (red[2][0][l] + red[3][0][l]);
     if (!fin) {
         if (m < M) store_f32x4<true>(slab + (size_t)sb * 16 * N, own);
@@ -230,9 +242,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restr
     asm volatile("" ::: "memory");
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     for (int s2 = 0; s2 + 1 < SB; ++s2)
-        if (m < M) a += *reinterpret_cast<const f32x4 *>(slab + (size_t)s2 * 16 * N);
+        if (m < M) a += load_f32x4_sc1(slab + (size_t)s2 * 16 * N);
     a += own;
-    if (timed_out) a = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+    if (timed_out) {
+        a = f32x4{__uint_as_float(0x7fc00000u), 0.f, 0.f, 0.f};
+        if (l == 0) (void)__hip_atomic_fetch_or(wait_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     red[0][0][l] = a;
     red[1][0][l] = red[2][0][l] = red[3][0][l] = f32x4{0.f, 0.f, 0.f, 0.f};
     resid_epilogue_step<H>(red, M, N, ntg, e, l, xpre);

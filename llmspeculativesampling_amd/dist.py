@@ -27,25 +27,21 @@ def pack_outputs(outs: Sequence[torch.Tensor], width: int, device) -> torch.Tens
 
 
 class TokenComm:
-    """One rank's membership in the RCCL communicator of the throughput-mode gather (sd_comm_* of include/specdec.h).
-    The 128-byte ncclUniqueId travels from rank 0 to the others over the existing torch.distributed group (its store /
-    broadcast is the side channel); the gather itself is ONE ncclAllGather issued by libspecdec on the current stream."""
+    """One rank's membership in the RCCL communicator of the throughput-mode gather (sd_comm_* of include/specdec.h),
+    created from the 128-byte ncclUniqueId every rank was handed (see _token_comm); the gather itself is ONE ncclAllGather
+    issued by libspecdec on the current stream."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, rank: int, world: int, ident: bytes, device):
         import ctypes as C
-        import torch.distributed as dist
         from ._lib import lib, check
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        ident = [None]
-        if self.rank == 0:
-            buf = (C.c_char * 128)()
-            check(lib.sd_comm_unique_id(buf), "sd_comm_unique_id")
-            ident[0] = bytes(buf)
-        dist.broadcast_object_list(ident, src=0, group=group)
+        self.rank, self.world = rank, world
+        self.device = torch.device(device)
         h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            check(lib.sd_comm_init(self.rank, self.world, ident[0], C.byref(h)), "sd_comm_init")
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                check(lib.sd_comm_init(self.rank, self.world, ident, C.byref(h)), "sd_comm_init")
+        else:
+            check(lib.sd_comm_init(self.rank, self.world, ident, C.byref(h)), "sd_comm_init")
         self.handle = h
 
     def all_gather_tokens(self, mine: torch.Tensor) -> torch.Tensor:
@@ -69,29 +65,75 @@ class TokenComm:
 _COMMS = {}
 
 
+def _agree(ok: bool, group, device) -> bool:
+    """True iff `ok` holds on EVERY rank (one all_reduce that every rank always takes part in)."""
+    import torch.distributed as dist
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag) == 1
+
+
 def _token_comm(group, device) -> Optional["TokenComm"]:
-    """The rank's TokenComm for this process group, or None when it could not be created on EVERY rank (the ranks agree
-    through one all_reduce, so they all take the same collective; the reason goes to stderr)."""
+    """The rank's TokenComm for this process group, or None when it could not be created on EVERY rank - in which case
+    the caller gathers through torch.distributed instead.
+
+    The SEQUENCE OF COLLECTIVES is the same on every rank whatever fails where (with a conditional broadcast a
+    rank that failed early went on to the next collective while the others still sat in the broadcast - a hang in the
+    very case the fallback exists for):
+      1. every rank probes RCCL locally (dlopen + symbol lookup, no communicator) -> all_reduce(MIN) of the result;
+         not resolvable somewhere: every rank returns None, no further collective;
+      2. rank 0 asks for the unique id; the broadcast ALWAYS runs and carries None when that failed;
+      3. ranks holding an id call sd_comm_init (ncclCommInitRank, itself collective: every rank is in it or none is);
+         all_reduce(MIN) of its outcome; any failure: every rank destroys what it created and returns None."""
+    import ctypes as C
     import sys
     import torch.distributed as dist
+    from ._lib import lib
     key = (id(group), str(device))
-    if key not in _COMMS:
-        comm, err = None, None
-        try:
-            comm = TokenComm(group, device)
-        except Exception as e:                                   # e.g. librccl not resolvable from libspecdec
-            err = e
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok) == 0:
-            if err is not None:
-                print(f"[dist] sd_comm_init failed on this rank ({type(err).__name__}: {err}); "
-                      "gathering through torch.distributed's RCCL all_gather instead", file=sys.stderr, flush=True)
+    if key in _COMMS:
+        return _COMMS[key]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    comm, why = None, None
+    try:
+        probe_ok = lib.sd_comm_probe() == 0
+        if not probe_ok:
+            why = lib.sd_last_error().decode(errors="replace")
+    except Exception as e:                                       # noqa: BLE001 - e.g. a library built without the entry
+        probe_ok, why = False, repr(e)
+    if _agree(probe_ok, group, device):
+        ident = [None]
+        if rank == 0:
+            try:
+                buf = (C.c_char * 128)()
+                if lib.sd_comm_unique_id(buf) == 0:
+                    ident[0] = bytes(buf)
+                else:
+                    why = lib.sd_last_error().decode(errors="replace")
+            except Exception as e:                               # noqa: BLE001
+                why = repr(e)
+        dist.broadcast_object_list(ident, src=0, group=group)    # unconditional: None tells the others to skip the init
+        if ident[0] is not None:
+            try:
+                comm = TokenComm(rank, world, ident[0], device)
+            except Exception as e:                               # noqa: BLE001
+                why = repr(e)
+        elif why is None:
+            why = "rank 0 could not create the unique id"
+        if not _agree(comm is not None, group, device):
             if comm is not None:
                 comm.close()
             comm = None
-        _COMMS[key] = comm
-    return _COMMS[key]
+    if comm is None:
+        print(f"[dist] rank {rank}: libspecdec's RCCL gather is unavailable ({why or 'failed on another rank'}); "
+              "gathering through torch.distributed's all_gather instead", file=sys.stderr, flush=True)
+    _COMMS[key] = comm
+    return comm
+
+
+def _use_own_collective(group, mine: torch.Tensor) -> bool:
+    """libspecdec's ncclAllGather needs an RCCL process group and GPU buffers (gloo / CPU tests take torch's all_gather)."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "nccl" and mine.is_cuda
 
 
 def gather_streams(outs: Sequence[torch.Tensor], n_streams: int, width: int, device=None,
@@ -108,7 +150,7 @@ def gather_streams(outs: Sequence[torch.Tensor], n_streams: int, width: int, dev
     if mine.shape[0] < per_rank:                      # ragged tail: pad with an all -1 row
         pad = torch.full((per_rank - mine.shape[0], width), -1, dtype=torch.int32, device=device)
         mine = torch.cat([mine, pad], 0)
-    comm = _token_comm(group, mine.device) if dist.get_backend(group) == "nccl" and mine.is_cuda else None
+    comm = _token_comm(group, mine.device) if _use_own_collective(group, mine) else None
     if comm is not None:
         gathered = comm.all_gather_tokens(mine.contiguous())
     else:

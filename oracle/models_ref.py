@@ -67,8 +67,16 @@ def _tree_bias(bias, extra_attention_mask, dtype):
     return bias
 
 
+def _kv_fp8(t: torch.Tensor) -> torch.Tensor:
+    """fp8 (OCP e4m3, scale 1) KV arena of BASELINE config 5 - NO reference counterpart (the reference keeps K / V in the
+    model dtype): a new K / V row is stored as e4m3 (round to nearest even, clamped to +-448) and read back exactly.  The
+    oracle applies the same quantisation where the row joins the cache, so that a 16-bit forward with an fp8 arena can be
+    held to the same 'no further from the fp32 truth than the reference arithmetic' rule as one with a 16-bit arena."""
+    return t.float().clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+
+
 def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Optional[KV],
-                  extra_attention_mask=None, position_ids=None):
+                  extra_attention_mask=None, position_ids=None, kv_quant=None):
     dt = sd["model.embed_tokens.weight"].dtype
     H, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     B, q_len = ids.shape          # B > 1 only for the width-w drafts of multi_speculative_sampling (oracle/multi_ref.py)
@@ -90,6 +98,8 @@ def llama_forward(cfg, sd: Dict[str, torch.Tensor], ids: torch.Tensor, past: Opt
         v = F.linear(h, sd[p + "self_attn.v_proj.weight"]).view(B, q_len, Hkv, D).transpose(1, 2)
         q = q * cos + _rot_half(q) * sin
         k = k * cos + _rot_half(k) * sin
+        if kv_quant == "fp8":
+            k, v = _kv_fp8(k), _kv_fp8(v)
         if past:
             k = torch.cat([past[li][0], k], dim=2)
             v = torch.cat([past[li][1], v], dim=2)
@@ -175,7 +185,9 @@ class RefCausalLM:
     """Callable with the surface the reference touches: ``model(ids, past_key_values=, use_cache=)``
     -> ``.logits`` / ``.past_key_values``; ``.config.is_encoder_decoder``; ``.device``."""
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor]):
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], kv_quant: Optional[str] = None):
+        assert kv_quant in (None, "fp8") and (kv_quant is None or cfg.arch == "llama")
+        self.kv_quant = kv_quant                      # "fp8": the e4m3 KV arena of config 5 (_kv_fp8; not in the reference)
         self.cfg = cfg
         self.config = SimpleNamespace(is_encoder_decoder=False, vocab_size=cfg.vocab_size)
         self.sd = state_dict
@@ -185,6 +197,7 @@ class RefCausalLM:
     @torch.no_grad()
     def __call__(self, input_ids, past_key_values=None, use_cache=True, extra_attention_mask=None, position_ids=None, **_):
         fwd = llama_forward if self.cfg.arch == "llama" else opt_forward
-        logits, kv = fwd(self.cfg, self.sd, input_ids, past_key_values, extra_attention_mask, position_ids)
+        kw = {"kv_quant": self.kv_quant} if self.kv_quant else {}
+        logits, kv = fwd(self.cfg, self.sd, input_ids, past_key_values, extra_attention_mask, position_ids, **kw)
         self.n_calls += 1
         return SimpleNamespace(logits=logits, past_key_values=kv)

@@ -6,6 +6,7 @@ The device RNG is replayed into the oracle through sd_philox_exp / sd_philox_uni
 comparison is token for token, not statistical.
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -109,21 +110,24 @@ def test_native_device_loop_equals_oracle_on_the_device_rng_stream(hip, name, ki
     assert gd["approx_time"] > 0 and gd["target_time"] > 0 and gd["target_model_time"] == gd["target_time"]
 
 
-def test_stream_batched_loop_equals_oracle_per_stream(hip):
-    """speculative_sampling_batch (throughput mode: B streams through shared weight passes) against B separate oracle
-    runs, each fed its own stream's Philox variates; one stream stops at EOS while the others continue."""
+@pytest.mark.parametrize("gamma,n_streams", [(4, 4), (2, 4), (8, 8)], ids=["g4x4", "g2x4", "g8x8_two_passes"])
+def test_stream_batched_loop_equals_oracle_per_stream(hip, gamma, n_streams):
+    """speculative_sampling_batch (throughput mode: B streams through shared weight passes, the native lock-step loop
+    sd_spec_batch_generate) against B separate oracle runs, each fed its own stream's Philox variates; one stream stops
+    at EOS while the others continue.  gamma = 2 / 4 / 8 is config 4's sweep; 8 streams x 9 rows = 72 verify rows exceed
+    one pass's row budget, so that case also covers the loop's split into passes of whole streams."""
     dc, dsd, tc, tsd = _pair("corr", seed=21)
     V = dc.vocab_size
-    prompts = [torch.from_numpy(np.random.default_rng(40 + i).integers(3, V, size=(1, 9 + 2 * i))) for i in range(4)]
-    seeds = [900 + i for i in range(4)]
-    kw = dict(gamma=4, top_k=20, top_p=0.9)
+    prompts = [torch.from_numpy(np.random.default_rng(40 + i).integers(3, V, size=(1, 9 + 2 * i))) for i in range(n_streams)]
+    seeds = [900 + i for i in range(n_streams)]
+    kw = dict(gamma=gamma, top_k=20, top_p=0.9)
     od, ot = oracle.RefCausalLM(dc, dsd), oracle.RefCausalLM(tc, tsd)
-    probe = oracle.speculative_sampling(prompts[1], od, ot, -1, None, 24, noise=PhiloxOracleNoise(hip.lib, seeds[1], 4, _st), **kw)
+    probe = oracle.speculative_sampling(prompts[1], od, ot, -1, None, 24, noise=PhiloxOracleNoise(hip.lib, seeds[1], gamma, _st), **kw)
     eos = int(probe[0, prompts[1].shape[1] + 6])
     wants = []
     for p, sd_ in zip(prompts, seeds):
         wants.append(oracle.speculative_sampling(p, od, ot, eos, None, 24, details=True,
-                                                 noise=PhiloxOracleNoise(hip.lib, sd_, 4, _st), **kw))
+                                                 noise=PhiloxOracleNoise(hip.lib, sd_, gamma, _st), **kw))
     dm = hip.engine.SpecDecModel.from_state_dict(dc, dsd, dtype=torch.float32)
     tm = hip.engine.SpecDecModel.from_state_dict(tc, tsd, dtype=torch.float32)
     outs, ds = hip.S.speculative_sampling_batch([p.cuda() for p in prompts], dm, tm, eos, None, 24, details=True,
@@ -133,7 +137,8 @@ def test_stream_batched_loop_equals_oracle_per_stream(hip):
         np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
         assert gd["acc_len"] == wd["acc_len"] and gd["target_call_times"] == wd["target_call_times"]
         stopped += int(want[0, -1]) == eos
-    assert 1 <= stopped < 4
+    assert 1 <= stopped < n_streams
+    assert 0 < sum(sum(wd["acc_len"]) for _, wd in wants) < gamma * sum(len(wd["acc_len"]) for _, wd in wants)
 
 
 def test_autoregressive_device_rng_equals_oracle(hip):
@@ -485,65 +490,54 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     assert float((got - want[: got.shape[0]]).abs().max()) <= 0.04 * float(want.abs().max())
 
 
-# --------------------------------------------------------------------------- chained layer launch (chain_kernels.h)
-CHAIN_CFGS = {
-    "llama_h1024": dict(arch="llama", vocab_size=16384, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3,
-                        num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=256, rms_norm_eps=1e-5),
-    "llama_gqa_h2048": dict(arch="llama", vocab_size=16384, hidden_size=2048, intermediate_size=5632, num_hidden_layers=2,
-                            num_attention_heads=16, num_key_value_heads=4, max_position_embeddings=256, rms_norm_eps=1e-6),
-    "opt_h1024": dict(arch="opt", vocab_size=16384, hidden_size=1024, ffn_dim=4096, num_hidden_layers=3,
-                      num_attention_heads=16, max_position_embeddings=256, do_layer_norm_before=True,
-                      word_embed_proj_dim=1024),
-}
-
-
-def _chain_status(hip, ses):
+# --------------------------------------------------------------------------- bounded in-launch waits of the fused launches
+def _fused_status(hip, ses):
     import ctypes as C
+    torch.cuda.synchronize()
     w = C.c_uint(0)
-    assert hip.lib.sd_session_chain_status(ses.handle, C.byref(w)) == 0, hip.lib.sd_last_error().decode()
+    assert hip.lib.sd_session_fused_status(ses.handle, C.byref(w)) == 0, hip.lib.sd_last_error().decode()
     return w.value
 
 
-@pytest.mark.parametrize("mode", ["1", "2"], ids=["inorder", "engine"])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("name", list(CHAIN_CFGS))
-def test_chained_layer_launch_is_bit_identical_to_the_launch_per_op_path(hip, name, dtype, mode):
-    """SD_CHAIN=1: O -> residual+norm -> gate/up -> down -> residual+norm -> next QKV run as phases of ONE launch per
-    layer (workgroups of a phase prefetch their weights, then wait for the phase before them).  Arithmetic and split
-    plans are the per-op path's, so logits and every KV row must be bit-identical for 1..16 new rows, repeatedly (a stale
-    read across XCDs would show as a mismatch).  A wait that hits its time limit makes the forward fail (SD_ERR_HIP with
-    the status word), never return: either every call succeeds with identical bits, or the error is the documented one."""
-    cfg = ModelConfig(**CHAIN_CFGS[name])
-    sd = make_state_dict(cfg, 91, dtype=dtype)
-    m = hip.engine.SpecDecModel.from_state_dict(cfg, sd, dtype=dtype)
-    ids = torch.from_numpy(np.random.default_rng(23).integers(3, cfg.vocab_size, size=(1, 120))).to(torch.int32).cuda()[0]
-    steps = (5, 1, 5, 16, 3, 5, 5, 2, 5, 9)
-    outs = {}
-    for flag in ("0", mode):
-        os.environ["SD_CHAIN"] = flag
-        os.environ["SD_FUSE_ATTN_O"] = "0"                        # the chained launches keep the per-op O projection's k-split
-        os.environ["SD_NORM_ON_LOAD"] = "0"                       # ... and residual_norm_kernel's order of adding up a row's squares
-        try:
-            ses = m.new_session(160)
-            try:
-                ses.forward(ids[:40], 0)
-                got, pos = [], 40
-                for q in steps:
-                    got.append(ses.forward(ids[pos:pos + q], q).clone())
-                    pos += q
-            except hip.L.SpecDecError as e:
-                # status contract (ADVICE r2): a chained forward whose bounded waits expired (the engine's workgroups
-                # were not all resident) FAILS with the status word in the message - it never returns stale logits
-                assert flag != "0" and "status" in str(e) and "time limit" in str(e), e
-                return
-            outs[flag] = (torch.cat(got), ses.kv[:, :, :, :pos].clone())
-            assert _chain_status(hip, ses) == 0                   # a forward that returned has a clean status word
-        finally:
-            os.environ.pop("SD_CHAIN", None)
-            os.environ.pop("SD_FUSE_ATTN_O", None)
-            os.environ.pop("SD_NORM_ON_LOAD", None)
-    assert torch.equal(outs[mode][1], outs["0"][1]), "KV rows differ"
-    assert torch.equal(outs[mode][0], outs["0"][0]), "logits differ"
+def test_fused_launch_wait_timeout_surfaces_as_norm_logits_error(hip):
+    """VERDICT r3 item 8 / ADVICE r3: the in-launch waits of the fused attention + O launch and of the k-split down
+    projection are bounded; when a bound is hit the launch must NOT return plausible numbers.  A test hook
+    (sd_session_test_skew_wait) makes the fused launches of ONE forward expect an arrival that never comes: every wait of
+    that forward runs into its 20 ms limit, the logits must be NaN in every row, the sampler must raise the reference's
+    RuntimeError('norm logits error') (utils.py:186-188), the session's status word must name both kinds of wait - and
+    the forward after that must be back in step (counters re-zeroed, same logits as an undisturbed session, no further
+    status bit): one failed launch does not break the session."""
+    cfg = ModelConfig(arch="llama", vocab_size=4096, hidden_size=1024, intermediate_size=2048, num_hidden_layers=2,
+                      num_attention_heads=8, num_key_value_heads=8, max_position_embeddings=128, rms_norm_eps=1e-5)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=5, dtype=torch.bfloat16)
+    ids = torch.from_numpy(np.random.default_rng(3).integers(3, cfg.vocab_size, size=(1, 40))).to(torch.int32).cuda()[0]
+    ref = m.new_session(64)
+    ref.forward(ids[:20], 0)
+    want5 = ref.forward(ids[20:25], 5).clone()
+    want3 = ref.forward(ids[25:28], 3).clone()
+    ses = m.new_session(64)
+    ses.forward(ids[:20], 0)
+    ses.profile(True)                                             # the 5-row forward takes the fused launches ...
+    got = ses.forward(ids[20:25], 5).clone()
+    prof = ses.profile_read()
+    ses.profile(False)
+    assert torch.equal(got, want5) and prof["norm_residual"][1] == 1 and _fused_status(hip, ses) == 0
+    ses.rollback(20)
+    assert hip.lib.sd_session_test_skew_wait(ses.handle, 1) == 0
+    t0 = time.time()
+    bad = ses.forward(ids[20:25], 5).clone()
+    torch.cuda.synchronize()
+    assert 0.02 <= time.time() - t0 < 5.0                          # 2 layers x 2 bounded waits of 20 ms, not a hang
+    assert bool(torch.isnan(bad).any(dim=1).all()), "a timed-out fused launch returned finite logit rows"
+    with pytest.raises(RuntimeError, match="norm logits error"):
+        hip.S.norm_logits(bad[:1].clone(), 1.0, 20, 0.9)
+    assert _fused_status(hip, ses) == 3                            # bit 0: attention + O, bit 1: down projection
+    assert _fused_status(hip, ses) == 0                            # (read clears)
+    ses.rollback(20)
+    again = ses.forward(ids[20:25], 5).clone()                     # re-synchronised: the very next forward is clean
+    assert torch.equal(again, want5)
+    assert torch.equal(ses.forward(ids[25:28], 3), want3)
+    assert _fused_status(hip, ses) == 0
 
 
 # --------------------------------------------------------------------------- config 3: OPT in bf16 end to end

@@ -47,26 +47,34 @@ def _host_sd(m):
     return sd
 
 
-def _truth_errors(hip, cfg, seed, label, transform=None):
+def _truth_errors(hip, cfg, seed, label, transform=None, prefill=23, verify=5, check_launches=None):
     """HIP bf16 forward and oracle bf16 forward against the oracle fp32 forward of the same bf16-valued weights:
-    a 23-row prefill, then a gamma+1 = 5-row verify whose logits are compared.  Returns the oracle's bf16 logits too."""
-    m = hip.engine.SpecDecModel.synthetic(cfg, seed=seed, dtype=torch.bfloat16, max_pos=64, transform=transform)
+    a `prefill`-row prefill, then a `verify`-row verify (gamma + 1 = 5 by default) whose logits are compared.  Returns the
+    oracle's bf16 logits too.  check_launches(profile dict) may assert which launch classes the verify took."""
+    n = prefill + verify
+    max_pos = max(64, (n + 63) // 64 * 64)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=seed, dtype=torch.bfloat16, max_pos=max_pos, transform=transform)
     sd16 = _host_sd(m)
-    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 28)))
-    ses = m.new_session(64)
-    ses.forward(ids[0, :23].to(torch.int32).cuda(), 0)
-    got = ses.forward(ids[0, 23:28].to(torch.int32).cuda(), 5).cpu()
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, n)))
+    ses = m.new_session(max_pos)
+    ses.forward(ids[0, :prefill].to(torch.int32).cuda(), 0)
+    if check_launches is not None:
+        ses.profile(True)
+    got = ses.forward(ids[0, prefill:n].to(torch.int32).cuda(), verify).cpu()
+    if check_launches is not None:
+        check_launches(ses.profile_read())
+        ses.profile(False)
     del ses, m
     torch.cuda.empty_cache()
     o16 = oracle.RefCausalLM(cfg, sd16)
-    r = o16(ids[:, :23])
-    ref16 = o16(ids[:, 23:28], past_key_values=r.past_key_values).logits.float()[0]
+    r = o16(ids[:, :prefill])
+    ref16 = o16(ids[:, prefill:n], past_key_values=r.past_key_values).logits.float()[0]
     del o16, r
     sd32 = {k: v.float() for k, v in sd16.items()}
     del sd16
     o32 = oracle.RefCausalLM(cfg, sd32)
-    r = o32(ids[:, :23])
-    truth = o32(ids[:, 23:28], past_key_values=r.past_key_values).logits.float()[0]
+    r = o32(ids[:, :prefill])
+    truth = o32(ids[:, prefill:n], past_key_values=r.past_key_values).logits.float()[0]
     del o32, r, sd32
     e_hip, e_ref = float((got - truth).abs().max()), float((ref16 - truth).abs().max())
     rms_hip = float((got - truth).pow(2).mean().sqrt())
@@ -279,34 +287,135 @@ def test_mfma_path_token_for_token_vs_oracle_on_exact_gemm_pair(hip, name, frac,
     assert torch.equal(got, got2) and gd["acc_len"] == gd2["acc_len"]
 
 
-@pytest.mark.parametrize("n_streams", [8, 12], ids=["40rows", "60rows"])
-def test_stream_batched_verify_13b_layer_shape_error_vs_fp32_truth(hip, n_streams):
-    """Throughput mode at the production layer shape ("a bf16 batched-vs-oracle test"): 8 / 12 streams
-    x (gamma + 1) = 40 / 60 verify rows through ONE pass of a 2-layer model with Llama-2-13b's layer shape - the balanced
-    many-row GEMM (gemm_bf16_rows) with its fused QKV / SiLU epilogues, per-stream attention groups, batched prefill of the
-    prompts - against the oracle run stream by stream.  Bar: per stream, the HIP logits' error against an fp32 forward of
-    the same bf16-valued weights is at most 1.5x the error of the reference's bf16 arithmetic (the rule of this file)."""
-    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2,
-                      num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=256, rms_norm_eps=1e-5)
+def _llama13b_layers(depth):
+    return ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=depth,
+                       num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=256, rms_norm_eps=1e-5)
+
+
+@pytest.mark.parametrize("verify", [5, 9], ids=["5rows", "9rows"])
+def test_llama13b_shape_verify_at_bench_context_vs_fp32_truth(hip, verify):
+    """the oracle check at the BENCH's context length.  2 layers of the 13b layer shape, a 200-row
+    prefill (the LDS-tiled prefill GEMMs, 25 attention groups) and then a 5-row and a 9-row verify at S = 205 / 209 - the
+    fused attention + O launch with its write-through / counter hand-off (two row groups at 9 rows), both norm-on-load
+    seams and the k-split down projection with the residual epilogue at 5 rows, the residual+norm launches at 9 - held to
+    the fp32 truth under the 1.5x rule.  Until now that context was only ever compared with the unfused HIP path."""
+    def launches(prof):
+        # 5 rows: of 2 x 2 residual+norm launches only the final norm's is left (both seams normalise on load); the
+        # attention class (2 launches = 2 layers) is the fused attention + O launch: the GEMM class has no O projection
+        n_gemm = prof["gemm"][1]
+        assert prof["attention"][1] == 2
+        if verify <= 8:
+            assert prof["norm_residual"][1] == 1 and n_gemm == 2 * 3 + 1, prof
+        else:
+            assert n_gemm == 2 * 3 + 1, prof                    # fused attention + O also at 9 rows (two row groups)
+    _, _, _, errs = _truth_errors(hip, _llama13b_layers(2), seed=9, label=f"llama-13b shape, 200-row prefill, {verify}-row verify",
+                                  prefill=200, verify=verify, check_launches=launches)
+    _assert_within_reference_error(errs, f"S~200, {verify} rows")
+
+
+@pytest.mark.parametrize("n_streams,gamma", [(8, 4), (12, 4), (8, 2), (8, 8)], ids=["40rows", "60rows", "g2_24rows", "g8_72rows"])
+def test_stream_batched_verify_13b_layer_shape_error_vs_fp32_truth(hip, n_streams, gamma):
+    """Throughput mode at the production layer shape: 8 / 12 streams x (gamma + 1) verify
+    rows - 40 / 60 rows at gamma = 4, 24 rows at gamma = 2, 72 rows at gamma = 8 (config 4's sweep) - through a 2-layer model
+    with Llama-2-13b's layer shape: the balanced many-row GEMM (gemm_bf16_rows) with its fused QKV / SiLU epilogues,
+    per-stream attention groups (two per stream at 9 rows), batched prefill of the prompts - against the oracle run stream
+    by stream.  Bar: per stream, the HIP logits' error against an fp32 forward of the same bf16-valued weights is at most
+    1.5x the error of the reference's bf16 arithmetic (the rule of this file).  A pass carries at most
+    engine.MAX_ROWS_PER_FORWARD rows: more streams than fit go through further passes of whole streams, as the native
+    loop does."""
+    cfg = _llama13b_layers(2)
+    q = gamma + 1
     m = hip.engine.SpecDecModel.synthetic(cfg, seed=9, dtype=torch.bfloat16, max_pos=96)
     sd16 = _host_sd(m)
     sd32 = {k: v.float() for k, v in sd16.items()}
     o16, o32 = oracle.RefCausalLM(cfg, sd16), oracle.RefCausalLM(cfg, sd32)
     rng = np.random.default_rng(21)
     lens = [int(x) for x in rng.integers(9, 40, size=n_streams)]
-    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(L + 5,)).astype(np.int32)).cuda() for L in lens]
+    seqs = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(L + q,)).astype(np.int32)).cuda() for L in lens]
     sessions = [m.new_session(96) for _ in lens]
     hip.engine.batch_prefill(sessions, seqs, lens)
-    got = hip.engine.batch_forward(sessions, seqs, [5] * n_streams, [5] * n_streams).cpu()
+    per_pass = max(1, hip.engine.MAX_ROWS_PER_FORWARD // q)
+    got = torch.cat([hip.engine.batch_forward(sessions[a:a + per_pass], seqs[a:a + per_pass], [q] * len(sessions[a:a + per_pass]),
+                                              [q] * len(sessions[a:a + per_pass])).cpu().clone()
+                     for a in range(0, n_streams, per_pass)])
     worst = (0.0, 0.0)
     for i, (L, sq) in enumerate(zip(lens, seqs)):
         ids = sq[None].long().cpu()
-        ref16 = o16(ids).logits.float()[0, L:L + 5]
-        truth = o32(ids).logits.float()[0, L:L + 5]
-        mine = got[5 * i:5 * i + 5]
+        ref16 = o16(ids).logits.float()[0, L:L + q]
+        truth = o32(ids).logits.float()[0, L:L + q]
+        mine = got[q * i:q * i + q]
         e_hip, e_ref = float((mine - truth).abs().max()), float((ref16 - truth).abs().max())
         r_hip, r_ref = float((mine - truth).pow(2).mean().sqrt()), float((ref16 - truth).pow(2).mean().sqrt())
         worst = max(worst, (e_hip / max(e_ref, 1e-9), r_hip / max(r_ref, 1e-9)))
         assert r_hip <= 1.5 * r_ref + 1e-3, (i, L, r_hip, r_ref)
         assert e_hip <= 1.5 * e_ref + 0.02, (i, L, e_hip, e_ref)
-    print(f"{n_streams} streams: worst (max-error ratio, rms ratio) HIP / reference-bf16 = ({worst[0]:.2f}, {worst[1]:.2f})")
+    print(f"{n_streams} streams x {q} rows: worst (max-error ratio, rms ratio) HIP / reference-bf16 = ({worst[0]:.2f}, {worst[1]:.2f})")
+
+
+def test_tp8_loopback_llama70b_shard_shape_fp8_kv_vs_fp32_truth(hip):
+    """VERDICT r3 item 1(a) - BASELINE config 5 as far as ONE GPU allows: an 8-way tensor-parallel target at Llama-2-70b's
+    layer shape (hidden 8192; per rank 8 of 64 query heads, 1 of 8 KV heads, 3584 of 28672 MLP columns; row-parallel
+    O: K = 1024, down: K = 3584, both folded over the group), 2 layers, bf16 weights, fp8 (e4m3) KV arenas, all eight
+    ranks in one process through the loopback group (the kernels and tp_reduce of the RCCL path; the all-reduce is an
+    in-process rendezvous + sum kernel).  A 40-row prefill (the many-row GEMMs under TP) and a 5-row verify:
+      * every rank's logits are bit-identical to every other rank's (same all-reduced sums everywhere);
+      * the verify rows obey the rule of this file against an fp32 forward of the same weights (modeling_llama.py:225-234,
+        292-393; oracle.RefCausalLM), where the reference arithmetic is the oracle run in bf16 WITH the same e4m3
+        quantisation of new K / V rows (oracle models_ref._kv_fp8 - the fp8 arena has no reference counterpart, so the
+        quantisation is part of the configuration, not of the error being judged);
+      * the unsharded engine with an fp8 arena obeys the same rule (config 5's shape on one GPU, as the bench runs it);
+      * each rank's arena holds its own KV head: e4m3 bytes equal to the unsharded engine's up to the last bit of a
+        bf16 K / V value that sits on an e4m3 rounding boundary."""
+    from llmspeculativesampling_amd import tp
+    from test_gpu_native_parity import _run_ranks
+    W = 8
+    cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=8192, intermediate_size=28672, num_hidden_layers=2,
+                      num_attention_heads=64, num_key_value_heads=8, max_position_embeddings=128, rms_norm_eps=1e-5)
+    full = hip.engine.SpecDecModel.synthetic(cfg, seed=17, dtype=torch.bfloat16, max_pos=64)
+    sd16 = _host_sd(full)
+    groups = tp.TPGroup.loopback(W)
+    shards = [tp.shard_model(cfg, sd16, r, W, group=groups[r], dtype=torch.bfloat16, max_pos=64) for r in range(W)]
+    lc = shards[0].cfg
+    assert (lc.num_attention_heads, lc.num_key_value_heads, lc.intermediate_size, lc.head_dim, lc.hidden_size) == (8, 1, 3584, 128, 8192)
+    ids = torch.from_numpy(np.random.default_rng(4).integers(3, cfg.vocab_size, size=(1, 45)))
+    dev_ids = ids[0].to(torch.int32).cuda()
+    sess = [m.new_session(64, kv_dtype="fp8") for m in shards]
+    _run_ranks([lambda r=r: sess[r].forward(dev_ids[:40], 0) for r in range(W)])
+    got = _run_ranks([lambda r=r: sess[r].forward(dev_ids[40:45], 5).clone() for r in range(W)])
+    for r in range(1, W):
+        assert torch.equal(got[r], got[0]), f"rank {r} differs from rank 0"
+    fs = full.new_session(64, kv_dtype="fp8")
+    fs.forward(dev_ids[:40], 0)
+    got_full = fs.forward(dev_ids[40:45], 5).clone().cpu()
+    kv_full = fs.kv.clone()
+    tp_logits = got[0].cpu()
+    kv_ranks = [s_.kv.clone() for s_ in sess]
+    del sess, shards, groups, fs, full
+    torch.cuda.empty_cache()
+    o16 = oracle.RefCausalLM(cfg, sd16, kv_quant="fp8")
+    r_ = o16(ids[:, :40])
+    ref16 = o16(ids[:, 40:45], past_key_values=r_.past_key_values).logits.float()[0]
+    del o16, r_
+    sd32 = {k: v.float() for k, v in sd16.items()}
+    del sd16
+    o32 = oracle.RefCausalLM(cfg, sd32)
+    r_ = o32(ids[:, :40])
+    truth = o32(ids[:, 40:45], past_key_values=r_.past_key_values).logits.float()[0]
+    del o32, r_, sd32
+    for name, mine in (("tp8 loopback", tp_logits), ("unsharded", got_full)):
+        e_hip, e_ref = float((mine - truth).abs().max()), float((ref16 - truth).abs().max())
+        r_hip, r_ref = float((mine - truth).pow(2).mean().sqrt()), float((ref16 - truth).pow(2).mean().sqrt())
+        print(f"70b shard shape, fp8 KV, {name}: |logit| max {float(truth.abs().max()):.2f}; max err hip {e_hip:.4f} ref {e_ref:.4f}; "
+              f"rms hip {r_hip:.5f} ref {r_ref:.5f}")
+        _assert_within_reference_error((e_hip, e_ref, r_hip, r_ref), name)
+    # rank r's arena = KV head r of the unsharded arena: layer 0 depends on the embeddings alone, so its bytes must agree
+    # except where a bf16 K / V value computed in another summation order straddles an e4m3 rounding boundary
+    for r in range(W):
+        assert tuple(kv_ranks[r].shape) == (2, 2, 1, 64, 128) and kv_ranks[r].dtype == torch.uint8
+        mine, ref = kv_ranks[r][0, :, 0, :45], kv_full[0, :, r, :45]
+        assert float((mine != ref).float().mean()) < 0.02, (r, float((mine != ref).float().mean()))
+        a = mine.view(torch.float8_e4m3fn).float()
+        b = ref.view(torch.float8_e4m3fn).float()
+        assert bool(((a - b).abs() <= 0.126 * torch.maximum(a.abs(), b.abs()) + 2e-3).all())      # one e4m3 step at most
+
+

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     raw = C.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert _lib.lib.sd_version() == 3           # a host-only call: no GPU needed
+    assert _lib.lib.sd_version() == 4           # a host-only call: no GPU needed
 
 
 def test_struct_layouts_match_header():
@@ -152,6 +152,92 @@ def test_gather_streams_world_size_2_gloo(n_streams):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in got)
     assert all(t == 2.0 for _, _, t in got)
+
+
+def _gloo_fallback_worker(rank, world, port, mode, q):
+    """gather_streams with libspecdec's own collective REQUESTED (as on an RCCL group) but failing in `mode`:
+    'probe' - RCCL not resolvable on rank 1 only; 'id' - rank 0 cannot create the unique id; 'init' - sd_comm_init fails
+    on rank 1 only (rank 0's succeeds: a stub handle); 'ok' - every step succeeds (stub collective)."""
+    import ctypes as C
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from llmspeculativesampling_amd import dist as D
+    from llmspeculativesampling_amd import _lib
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    calls = []
+
+    class FakeLib:
+        def sd_comm_probe(self):
+            calls.append("probe")
+            return 1 if (mode == "probe" and rank == 1) else 0
+
+        def sd_comm_unique_id(self, buf):
+            calls.append("id")
+            if mode == "id":
+                return 1
+            C.memmove(buf, bytes(range(128)), 128)
+            return 0
+
+        def sd_comm_init(self, r, w, ident, out):
+            calls.append("init")
+            assert bytes(ident) == bytes(range(128)) and (r, w) == (rank, world)
+            if mode == "init" and rank == 1:
+                return 1
+            out._obj.value = 0x1234                               # (byref(handle): a non-null stub communicator)
+            return 0
+
+        def sd_comm_destroy(self, h):
+            calls.append("destroy")
+            return 0
+
+        def sd_last_error(self):
+            return b"stub failure"
+    fake = FakeLib()
+    _lib.lib = fake                                           # dist.py imports `lib` from _lib at call time
+    D._use_own_collective = lambda group, mine: True          # as if the group were RCCL and the buffers on a GPU
+    gathered_by = []
+    real_all_gather = dist.all_gather
+    dist.all_gather = lambda *a, **k: (gathered_by.append("torch"), real_all_gather(*a, **k))[1]
+    D.TokenComm.all_gather_tokens = lambda self, mine: (gathered_by.append("own"), torch.stack(
+        [t for t in (lambda g: (real_all_gather(g, mine), g)[1])([torch.empty_like(mine) for _ in range(world)])]))[1]
+    outs = [torch.arange(5 + s, dtype=torch.int64).unsqueeze(0) + 100 * s for s in D.shard_streams(5, rank, world)]
+    res = D.gather_streams(outs, 5, width=32, device="cpu")
+    res2 = D.gather_streams(outs, 5, width=32, device="cpu")    # the decision is cached: no second negotiation
+    ok = all(r[s].tolist() == (torch.arange(5 + s) + 100 * s).tolist() for r in (res, res2) for s in range(5))
+    q.put((rank, ok, gathered_by, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["probe", "id", "init", "ok"])
+def test_gather_streams_fallback_never_hangs_world_size_2_gloo(mode):
+    """whichever step of creating libspecdec's RCCL communicator fails, on whichever rank, BOTH ranks
+    must take the same sequence of collectives, end up on torch.distributed's all_gather together and return the right
+    streams - the old code skipped a broadcast on the failing rank and hung the others.  Two gloo ranks with a stubbed
+    sd_comm_*; 'ok' checks that the own collective is used when every step succeeds."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30400 + (os.getpid() % 400) + {"probe": 0, "id": 1, "init": 2, "ok": 3}[mode]
+    procs = [ctx.Process(target=_gloo_fallback_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in got), got
+    want = "own" if mode == "ok" else "torch"
+    assert all(by == [want, want] for _, _, by, _ in got), got
+    calls = {r: c for r, _, _, c in got}
+    if mode == "probe":
+        assert calls[0] == ["probe"] and calls[1] == ["probe"]                    # nobody goes on to the id / init
+    elif mode == "id":
+        assert calls[0] == ["probe", "id"] and calls[1] == ["probe"]              # None was broadcast: no init anywhere
+    elif mode == "init":
+        assert calls[0] == ["probe", "id", "init", "destroy"] and calls[1] == ["probe", "init"]
+    else:
+        assert calls[0] == ["probe", "id", "init"] and calls[1] == ["probe", "init"]
 
 
 # --------------------------------------------------------------------------- evaluation-driver host pieces (8(f) rank 3)
@@ -375,7 +461,8 @@ def test_new_entry_points_reject_null_arguments_without_a_gpu():
         == _lib.SD_ERR_INVALID
     assert lib.sd_norm_probs_lists(None, 1, 32000, 32000, 1.0, 20, 0.9, 0, None, 32000, None, None, None, None) \
         == _lib.SD_ERR_INVALID
-    assert lib.sd_session_chain_status(None, None) == _lib.SD_ERR_INVALID
+    assert lib.sd_session_fused_status(None, None) == _lib.SD_ERR_INVALID
+    assert lib.sd_session_test_skew_wait(None, 1) == _lib.SD_ERR_INVALID and lib.sd_session_ao_stamps(None, None, 1) == _lib.SD_ERR_INVALID
     # round 3: the RCCL gather of the sharded streams (sd_comm_*) and the filter's dtype mode
     h = C.c_void_p()
     assert lib.sd_comm_init(0, 1, None, C.byref(h)) == _lib.SD_ERR_INVALID and b"sd_comm_init" in lib.sd_last_error()
