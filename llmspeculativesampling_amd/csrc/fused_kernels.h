@@ -54,7 +54,14 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
     // operand rows + per-tile sums of squares for the consumer's norm on load) instead of leaving the slab in `part`
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long *my_st = (stamps && (int)blockIdx.x < AO_STAMP_WGS) ? stamps + 8 * (size_t)blockIdx.x : nullptr;
-    auto stamp = [&](int slot) { if (my_st && threadIdx.x == 0) my_st[slot] = wall_clock64(); };
+    // (stamps stay in registers until the workgroup's last barrier is behind it: a store in front of a barrier must be
+    //  acknowledged before the barrier opens, which would stretch the phases being timed)
+    long long ts[6] = {0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int slot) { if (my_st) ts[slot] = wall_clock64(); };
+    auto flush_stamps = [&](int lo, int hi) {
+        if (my_st && threadIdx.x == 0)
+            for (int i = lo; i <= hi; ++i) my_st[i] = ts[i];
+    };
     const int n_att = Hq * tab.n_groups;                          // attention workgroups: (head, row group), head fastest
     if (my_st && threadIdx.x == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -75,6 +82,8 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
         __syncthreads();
         if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp(5);
+        flush_stamps(0, 0);
+        flush_stamps(4, 5);                                       // (1..3 were written by attn_body)
         return;
     }
     // ---- O projection of n-tiles 2 b and 2 b + 1 (b = blockIdx.x - Hq): 4 waves x a quarter of K each, weights first ----
@@ -160,4 +169,5 @@ __global__ __launch_bounds__(512, 2) void attn_oproj_kernel(const T *__restrict_
         gemm_epilogue_step<1, EPI_PART, 1, 1, T>(red, 0, part, M, 16, N, 0, ntg, e, tid4);
     }
     ostamp(4);
+    flush_stamps(0, 4);
 }

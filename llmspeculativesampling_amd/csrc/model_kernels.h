@@ -975,7 +975,10 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
                                           float *__restrict__ partial, int head, int bg, int bz, char *smem,
                                           long long *wg_stamps = nullptr) {
     // wg_stamps (or NULL): this workgroup's record of a stamped fused launch (fused_kernels.h, AO_STAMP_WGS): slots 1..3
-    auto wstamp = [&](int slot) { if (wg_stamps && threadIdx.x == 0) wg_stamps[slot] = wall_clock64(); };
+    // (kept in registers and written at the end: a store in front of a barrier has to be acknowledged before the barrier
+    //  lets the workgroup through - round trips that would stretch the very phases being timed)
+    long long wts[4] = {0, 0, 0, 0};
+    auto wstamp = [&](int slot) { if (wg_stamps) wts[slot] = wall_clock64(); };
     static_assert(!KV8 || (sizeof(T) == 2 && D >= 32), "fp8 KV needs a 16-bit model type and the MFMA score path");
     float *qs = reinterpret_cast<float *>(smem);                  // [TQ][D]
     constexpr int ATT_RG = 256 / (D / 8);                         // key groups of the P.V phase, each leaves a partial sum
@@ -1012,30 +1015,37 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
         const int g = s + kb - tab.tree_base;                     // index among the tree rows (< 0: a cached key)
         return g < 0 || ((tab.tree_mask[min(r0 + t, SD_MAX_ROWS - 1)] >> g) & 1ull);
     };
-    const T *K = karena + ((size_t)kvh * max_seq + kb) * D;
-    const T *Vv = karena + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
-    const unsigned char *K8 = karena8 + ((size_t)kvh * max_seq + kb) * D;
-    const unsigned char *V8 = karena8 + ((size_t)(Hkv + kvh) * max_seq + kb) * D;
+    // (an empty chunk - split attention past the visible keys - reads from the head's first key: loads are never branched
+    //  around, see below, so their addresses must be valid)
+    const int kb_ld = s_hi > 0 ? kb : 0, s_last = max(s_hi, 1) - 1;
+    const T *K = karena + ((size_t)kvh * max_seq + kb_ld) * D;
+    const T *Vv = karena + ((size_t)(Hkv + kvh) * max_seq + kb_ld) * D;
+    const unsigned char *K8 = karena8 + ((size_t)kvh * max_seq + kb_ld) * D;
+    const unsigned char *V8 = karena8 + ((size_t)(Hkv + kvh) * max_seq + kb_ld) * D;
     __shared__ float ml[ATT_TQ][2];
 
     // P.V operand prefetch: the V rows a thread will need do not depend on the scores, so their loads are issued
     // before QK^T / softmax and land while those run (up to VPF keys per thread: 256 keys at D = 128).  On the MFMA
     // path they go out right AFTER the first batch of K tiles, which is what the first phase waits for.
+    // NO BRANCH AROUND A LOAD (round 4, seen in the ISA): with `if (s2 < s_hi) load` hipcc's waitcnt insertion lost count
+    // at the joins and the first QK^T MFMA waited with vmcnt(3..0) - for all of K AND 13 of the 16 V loads behind it, i.e.
+    // the "prefetch" serialised 100 KB in front of the first score.  Every load is now unconditional on a clamped key
+    // index (a key past the range re-reads the last one; its value is never used: the P.V loop tests s < s_hi at USE),
+    // fp8 rows are widened at use, and the first MFMA waits for its own K tile only.
     constexpr int LPR_ = D / 8, NGRP_ = 256 / LPR_, VPF = 16;
     u32x4 vpre[VPF][sizeof(T) == 2 ? 1 : 2];
     auto issue_v = [&]() {
         const int dp = tid % LPR_, sg = tid / LPR_;
 #pragma unroll
         for (int j = 0; j < VPF; ++j) {
-            const int s2 = sg + j * NGRP_;
-            if (s2 < s_hi) {
-                if constexpr (KV8) {
-                    vpre[j][0] = fp8x8_to_16<T>(*reinterpret_cast<const uint2 *>(V8 + (size_t)s2 * D + dp * 8));
-                } else {
-                    const u32x4 *src = reinterpret_cast<const u32x4 *>(Vv + (size_t)s2 * D + dp * 8);
-                    vpre[j][0] = src[0];
-                    if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
-                }
+            const int s2 = min(sg + j * NGRP_, s_last);
+            if constexpr (KV8) {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(V8 + (size_t)s2 * D + dp * 8);
+                vpre[j][0] = u32x4{raw.x, raw.y, 0u, 0u};         // e4m3 bytes; widened in the P.V loop
+            } else {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(Vv + (size_t)s2 * D + dp * 8);
+                vpre[j][0] = src[0];
+                if (sizeof(T) == 4) vpre[j][sizeof(T) == 2 ? 0 : 1] = src[1];
             }
         }
     };
@@ -1056,38 +1066,43 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
         u32x4 qf[D / 32];
 #pragma unroll
         for (int dk = 0; dk < D / 32; ++dk)
-            qf[dk] = mrow < nr ? *reinterpret_cast<const u32x4 *>(qbuf + (size_t)(r0 + mrow) * Hq * D + head * D + dk * 32 + kq)
-                               : u32x4{0u, 0u, 0u, 0u};
+            qf[dk] = *reinterpret_cast<const u32x4 *>(qbuf + (size_t)(r0 + min(mrow, nr - 1)) * Hq * D + head * D + dk * 32 + kq);
         // key tiles are taken 4 at a time per wave with all of their K loads issued before the first MFMA
         // (a plain loop over tiles would pay one memory round trip per tile)
-        bool v_issued = false;
-        for (int kt0 = w; kt0 * 16 < s_hi; kt0 += 16) {
-            u32x4 kf[4][D / 32];
+        u32x4 kf[4][D / 32];
+        auto load_k = [&](int kt0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int kt = kt0 + 4 * u;
-                if (kt * 16 < s_hi) {
-                    if constexpr (KV8) {
-                        const unsigned char *kr8 = K8 + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
+                const int row = min((kt0 + 4 * u) * 16 + mrow, s_last);
+                if constexpr (KV8) {
+                    const unsigned char *kr8 = K8 + (size_t)row * D + kq;
 #pragma unroll
-                        for (int dk = 0; dk < D / 32; ++dk)
-                            kf[u][dk] = fp8x8_to_16<T>(*reinterpret_cast<const uint2 *>(kr8 + dk * 32));
-                    } else {
-                        const T *kr = K + (size_t)min(kt * 16 + mrow, s_hi - 1) * D + kq;
-#pragma unroll
-                        for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
+                    for (int dk = 0; dk < D / 32; ++dk) {
+                        const uint2 raw = *reinterpret_cast<const uint2 *>(kr8 + dk * 32);
+                        kf[u][dk] = u32x4{raw.x, raw.y, 0u, 0u};
                     }
+                } else {
+                    const T *kr = K + (size_t)row * D + kq;
+#pragma unroll
+                    for (int dk = 0; dk < D / 32; ++dk) kf[u][dk] = *reinterpret_cast<const u32x4 *>(kr + dk * 32);
                 }
             }
-            if (!v_issued) { issue_v(); v_issued = true; }
+        };
+        auto mul_k = [&](int kt0) {
+#pragma unroll
+            for (int dk = 0; dk < D / 32; ++dk)                   // rows >= nr of the q operand are zero
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qf[dk][i] = mrow < nr ? qf[dk][i] : 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int kt = kt0 + 4 * u;
                 if (kt * 16 >= s_hi) continue;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int dk = 0; dk < D / 32; ++dk)
-                    acc = mfma16<T>(kf[u][dk], qf[dk], acc);
+                for (int dk = 0; dk < D / 32; ++dk) {
+                    if constexpr (KV8) acc = mfma16<T>(fp8x8_to_16<T>(uint2{kf[u][dk][0], kf[u][dk][1]}), qf[dk], acc);
+                    else acc = mfma16<T>(kf[u][dk], qf[dk], acc);
+                }
                 if (mrow < ATT_TQ) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1100,8 +1115,16 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
                     }
                 }
             }
+        };
+        load_k(w);
+        asm volatile("" ::: "memory");                            // program order = queue order: K, then V
+        issue_v();
+        asm volatile("" ::: "memory");
+        mul_k(w);
+        for (int kt0 = w + 16; kt0 * 16 < s_hi; kt0 += 16) {      // (contexts past 256 keys per workgroup)
+            load_k(kt0);
+            mul_k(kt0);
         }
-        if (!v_issued) issue_v();                                 // a wave without a key tile of its own
     } else
     for (int s = tid; s < s_hi; s += 256) {
         float acc[ATT_TQ];
@@ -1262,7 +1285,12 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
                 const int s = sg + jj * NGRP;
                 if (s < s_hi) {
                     float v[8];
-                    unpack8<T>(vpre[jj], v);
+                    if constexpr (KV8) {
+                        const u32x4 vw[1] = {fp8x8_to_16<T>(uint2{vpre[jj][0][0], vpre[jj][0][1]})};
+                        unpack8<T>(vw, v);
+                    } else {
+                        unpack8<T>(vpre[jj], v);
+                    }
 #pragma unroll
                     for (int t = 0; t < NR; ++t) {
                         const float p = sc[(size_t)t * s_cap + s];
@@ -1330,6 +1358,7 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
             }
             store4_maybe_wt<WT>(out + xoff<T>(r0 + t, head * D + d, Hq * D), a[0], a[1], a[2], a[3]);
         }
+        if (wg_stamps && tid == 0) { wg_stamps[1] = wts[1]; wg_stamps[2] = wts[2]; wg_stamps[3] = wts[3]; }
     } else {
         for (int i = tid; i < nr * D; i += 256) {
             const int t = i / D, d = i - t * D;

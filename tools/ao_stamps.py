@@ -23,6 +23,8 @@ ap.add_argument("--rows", type=int, default=5)
 ap.add_argument("--prefix", type=int, default=190)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--flush", type=int, default=1, help="stream 1 GiB through the caches before every repetition")
+ap.add_argument("--prefetch", type=int, default=0, help="after the flush, read the whole KV arena once (torch reduction) - is a K / V "
+                "slice that was touched before the layer's QKV GEMM still close (Infinity Cache) when attention runs?")
 args = ap.parse_args()
 
 cfg = ModelConfig(arch="llama", vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=args.layers,
@@ -39,6 +41,8 @@ for rep in range(args.reps):
     if args.flush:
         junk.add_(1.0)
     ses.rollback(args.prefix)
+    if args.prefetch:
+        ses.kv.view(torch.int32).sum()
     ses.forward(ids[args.prefix:args.prefix + args.rows], args.rows)
     torch.cuda.synchronize()
     st = (C.c_longlong * (8 * n_wgs))()
