@@ -457,7 +457,9 @@ def main(argv=None):
     b_ver = algorithmic_verify_bytes(tm.cfg if TP > 1 else tcfg, args.gamma, S_mean, kvbytes=1 if args.kv_dtype == "fp8" else 2)
     if BS > 1:       # one pass over the weights serves BS streams; KV and logits scale with the stream count
         w_only = tcfg.n_params(streamed_only=True) * 2
-        b_ver = w_only * ((BS * (args.gamma + 1) + 63) // 64) + (b_ver - w_only) * BS
+        from llmspeculativesampling_amd.engine import MAX_ROWS_PER_FORWARD
+        per_pass = max(1, MAX_ROWS_PER_FORWARD // (args.gamma + 1))          # whole streams per pass (sd_spec_batch_generate)
+        b_ver = w_only * ((BS + per_pass - 1) // per_pass) + (b_ver - w_only) * BS
     achieved = b_ver / (t_ver * 1e-3) / 1e9 if ver_ms else float("nan")
     # HBM traffic per verify step from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and
     # WRITE_SIZE do not fit one pass and cannot be combined with the timed run), so the committed summary of the
@@ -505,7 +507,7 @@ def main(argv=None):
         roofline["op_classes_launches_per_verify"] = {k: v[1] // reps for k, v in prof.items()}
         if "gemm" in prof:
             g_ms = prof["gemm"][0] / reps
-            roofline["gemm_kernel"] = {"name": "the weight-streaming GEMM class: gemm_bf16_stream<MT=1,UNROLL=4,EPI,NTW=1> and its norm-on-load / residual-epilogue forms gemm_bf16_stream_xn, gemm_bf16_stream_fin (17-64 rows: gemm_bf16_rows)", "weight_bytes_per_verify": wbytes,
+            roofline["gemm_kernel"] = {"name": "the weight-streaming GEMM class: gemm_bf16_stream<MT=1,UNROLL=4,EPI,NTW=1> and its norm-on-load / residual-epilogue forms gemm_bf16_stream_xn, gemm_bf16_stream_fin (17-80 rows: gemm_bf16_rows)", "weight_bytes_per_verify": wbytes,
                                        "ms_per_verify": g_ms, "achieved_GBs": wbytes / (g_ms * 1e-3) / 1e9,
                                        "frac": wbytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 

@@ -237,11 +237,18 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
 // kernel.  Slab count: about 480 workgroups (measured optimum for all four shapes at 64, 128 and 256 rows).
 #define SD_MAX_FWD_ROWS 256
 struct GemmPlan { bool tiled; int S, ksp, mtw; };
-static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true) {
+struct RowsPlan { bool ok; int S, ksp, NG, grid, nwn, nwk, nld; };
+static RowsPlan rows_plan(int N, int K, int M, bool fused);
+#define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
+// fused: the caller wants the GEMM's whole k-range per workgroup (QKV / activation epilogue inside the launch)
+static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused = false) {
     GemmPlan p = {};
     const int KS = K / 32, Mpad = (int)align_up(M, 16);
     static const int tiled_min = getenv("SD_GEMM_TILED_MIN") ? atoi(getenv("SD_GEMM_TILED_MIN")) : 65;
-    if (x_tiled && M >= tiled_min && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
+    // (65..SD_MAX_ROWS rows - 8 streams x 9 verify rows - stay on the balanced one-workgroup-per-CU kernel, with its fused
+    //  epilogues, when both of its plans for the shape are good; prefill chunks of that size take it too)
+    const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= SD_MAX_ROWS && rows_plan(N, K, M, fused).ok;
+    if (x_tiled && M >= tiled_min && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
         p.tiled = true;
         p.mtw = Mpad <= 64 ? 2 : 4;
         const int MB = (Mpad / 16 + 2 * p.mtw - 1) / (2 * p.mtw), blocks = MB * (N / 16 / 8);
@@ -279,10 +286,9 @@ static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, 
 
 // ---- 17..64 rows: the balanced one-workgroup-per-CU kernel (rows_kernels.h).  S k-slabs x NG n-groups = one workgroup per
 // CU; a fused epilogue needs S == 1.  The plan minimises (weight bytes + slab traffic) / how evenly the n-tiles divide.
-struct RowsPlan { bool ok; int S, ksp, NG, grid, nwn, nwk, nld; };
 static RowsPlan rows_plan(int N, int K, int M, bool fused) {
     RowsPlan p = {};
-    if (!g_env.gemm_rows || M <= 16 || M > 64 || N % 16 || K % 32) return p;
+    if (!g_env.gemm_rows || M <= 16 || M > SD_MAX_ROWS || N % 16 || K % 32) return p;
     const int G = g_env.cus > 0 ? g_env.cus : 256, NT = N / 16, KS = K / 32, Mpad = (int)align_up(M, 16);
     const double wbytes = (double)N * K * 2.0, slab = 2.0 * Mpad * (double)N * 4.0;
     double best = 1e300;
@@ -305,6 +311,7 @@ static RowsPlan rows_plan(int N, int K, int M, bool fused) {
         // wave grid of a workgroup: nwn compute waves per k-group (one n-tile each) x nwk k-groups + loader waves, <= 16
         p.nwn = (NT + p.NG - 1) / p.NG;
         p.nwk = std::min(4, (16 - 1) / p.nwn);
+        if (Mpad > 64) p.nwk = std::min(p.nwk, 3);                 // (5 m-tiles: 2 x 4 k-groups x 4 k-steps x 5 KiB exceed the CU's LDS)
         p.nld = std::min(p.nwk, 16 - p.nwn * p.nwk);
     }
     return p;
@@ -341,6 +348,8 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
     else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{});
                         else if (ch == 6) go(integral_constant<int, 4>{}, integral_constant<int, 6>{});
                         else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); }
+    else if (MT == 5) { if (ch == 6) go(integral_constant<int, 5>{}, integral_constant<int, 6>{});       // (8 never fits at 5 m-tiles)
+                        else go(integral_constant<int, 5>{}, integral_constant<int, 4>{}); }
     else { sd_set_error("gemm_rows: %d rows", M); return SD_ERR_INVALID; }
     return SD_OK;
 }
@@ -423,7 +432,7 @@ extern "C" int sd_model_max_rows(const sd_model *m) {
     const int shapes[][2] = {{qkv_cols(c), c.hidden}, {c.hidden, q_dim(c)}, {gu_cols(c), c.hidden}, {c.hidden, c.inter},
                              {c.hidden, ed}, {ed, c.hidden}};
     for (int i = 0; i < (ed != c.hidden ? 6 : 4); ++i)
-        if (!gemm_plan(shapes[i][0], shapes[i][1], SD_MAX_FWD_ROWS).tiled) return SD_MAX_ROWS;
+        if (!gemm_plan(shapes[i][0], shapes[i][1], SD_MAX_FWD_ROWS).tiled) return SD_STREAM_MAX_ROWS;
     return SD_MAX_FWD_ROWS;
 }
 
@@ -841,13 +850,14 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
     if (is16(c.dtype)) {
+        bool xmap_identity = true;                                // (the tiled and the balanced kernel read whole activation tiles)
+        if (xtab)
+            for (int i = 0; i < M && xmap_identity; ++i) xmap_identity = xtab->xmap[i] == i;
+        if (xmap_identity) xtab = nullptr;                        // every row in place (a verify pass): no gather
         const GemmPlan pl = gemm_plan(N, K, M, xtab == nullptr);          // a row gather (lm_head) keeps the streaming kernel
         const int S = pl.S, ksp = pl.ksp;
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
-        bool xmap_identity = true;                                // (the balanced kernel reads whole activation tiles)
-        if (xtab)
-            for (int i = 0; i < M && xmap_identity; ++i) xmap_identity = xtab->xmap[i] == i;
         const RowsPlan rp = xmap_identity ? rows_plan(N, K, M, false) : RowsPlan{};
         if (pl.tiled) {
             launch_gemm_tiled<H>(W, X, s->part, M, Mpad, N, K, pl, st);
@@ -1295,7 +1305,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                 if ((rc = launch_gemm_xn<EPI_QKV_ROPE, H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, m->n1w[l], c.norm_eps, e, st)) != SD_OK)
                     return rc;
             }
-        } else if (fused && !gemm_plan(qkv_cols(c), H, n_new).tiled) {
+        } else if (fused && !gemm_plan(qkv_cols(c), H, n_new, true, true).tiled) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
             e.cos_t = (const H16 *)m->w.rope_cos; e.sin_t = (const H16 *)m->w.rope_sin;
@@ -1360,7 +1370,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             }
         }
         if (xn_o) {
-        } else if (fused && !gemm_plan(gu_cols(c), H, n_new).tiled) {
+        } else if (fused && !gemm_plan(gu_cols(c), H, n_new, true, true).tiled) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)ac; e.bias = (const H16 *)m->bfc1[l]; e.n_out = I;
             rc = llama ? run_gemm_fused<EPI_ACT_SILU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)
@@ -1525,7 +1535,9 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
     SD_REQUIRE(n_new >= 1 && pos0 >= 0, "sd_session_forward: n_new=%d pos0=%d", n_new, pos0);
     SD_REQUIRE(n_logits >= 0 && n_logits <= n_new, "sd_session_forward: n_logits=%d of n_new=%d", n_logits, n_new);
     SD_REQUIRE(n_logits == 0 || logits_out, "sd_session_forward: logits_out is null");
-    if (n_new > s->max_rows || n_new > SD_MAX_FWD_ROWS || n_logits > SD_MAX_ROWS || pos0 + n_new > s->max_seq) {
+    // (logit rows are gathered by the streaming kernel, <= 64 rows per call, unless every row of the call is one)
+    if (n_new > s->max_rows || n_new > SD_MAX_FWD_ROWS || n_logits > (n_logits == n_new ? SD_MAX_ROWS : SD_STREAM_MAX_ROWS) ||
+        pos0 + n_new > s->max_seq) {
         sd_set_error("sd_session_forward: n_new=%d (max_rows %d, <=%d), n_logits=%d (<=%d), pos0+n_new=%d (max_seq %d)",
                      n_new, s->max_rows, SD_MAX_FWD_ROWS, n_logits, SD_MAX_ROWS, pos0 + n_new, s->max_seq);
         return SD_ERR_CAPACITY;
@@ -1557,7 +1569,7 @@ extern "C" int sd_session_forward(sd_session *s, const int32_t *tokens, int n_ne
 extern "C" int sd_session_forward_tree(sd_session *s, const int32_t *tokens, const int32_t *positions, const uint64_t *masks,
                                        int n, int base_len, float *logits_out, long ld_logits, void *stream) {
     SD_REQUIRE(s && tokens && positions && masks && logits_out, "sd_session_forward_tree: null argument");
-    SD_REQUIRE(n >= 1 && n <= SD_MAX_ROWS && base_len >= 0, "sd_session_forward_tree: 1..%d nodes", SD_MAX_ROWS);
+    SD_REQUIRE(n >= 1 && n <= SD_MAX_TREE && base_len >= 0, "sd_session_forward_tree: 1..%d nodes", SD_MAX_TREE);
     if (n > s->max_rows || base_len + n > s->max_seq) {
         sd_set_error("sd_session_forward_tree: %d nodes after %d positions exceed max_rows %d / max_seq %d", n, base_len,
                      s->max_rows, s->max_seq);
@@ -1636,7 +1648,7 @@ extern "C" int sd_session_test_skew_wait(sd_session *s, int extra) {
 }
 
 extern "C" int sd_session_compact_kv(sd_session *s, int base_len, const int32_t *idx_dev, int k, void *stream) {
-    SD_REQUIRE(s && idx_dev && k >= 0 && k <= SD_MAX_ROWS && base_len >= 0 && base_len + k <= s->max_seq,
+    SD_REQUIRE(s && idx_dev && k >= 0 && k <= SD_MAX_TREE && base_len >= 0 && base_len + k <= s->max_seq,
                "sd_session_compact_kv: bad arguments");
     if (k == 0) return SD_OK;
     const sd_model_config &c = s->m->cfg;
@@ -1771,7 +1783,6 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, in
         if (splits_out) *splits_out = S;
         return SD_OK;
     }
-    SD_REQUIRE(M <= 64, "sd_gemm_bf16: more than 64 rows need the tile layout (x_tiled) and N %% 128 == 0");
     if (x_tiled) {
         const RowsPlan rp = rows_plan(N, K, M, false);
         if (rp.ok) {
@@ -1789,6 +1800,7 @@ extern "C" int sd_gemm_bf16(const void *w_packed, const void *x, int x_tiled, in
             return SD_OK;
         }
     }
+    SD_REQUIRE(M <= SD_STREAM_MAX_ROWS, "sd_gemm_bf16: more than 64 rows need the tile layout (x_tiled) and N %% 128 == 0");
     SD_REQUIRE((size_t)S * Mpad * N <= part_floats, "sd_gemm_bf16: part buffer needs %zu floats", (size_t)S * Mpad * N);
     hipStream_t st = (hipStream_t)stream;
     GemmEpi e = {};

@@ -24,7 +24,8 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
 // Row table of one forward, passed BY VALUE in the kernel arguments (no device copy to keep alive): rows may belong to
 // several independent sequences ("streams", SURVEY.md 8(e)/(f): stream-batched decode) that share the GEMMs and differ
 // in position, token source and KV arena.  A single-sequence forward is a table with one stream.
-#define SD_MAX_ROWS 64
+#define SD_MAX_ROWS 80                               // rows of one stream-batched pass (config 4: 8 streams x (gamma + 1 = 9) = 72)
+#define SD_MAX_TREE 64                               // nodes of a tree verify (ancestor masks are 64-bit words)
 #define SD_MAX_STREAMS 16
 #define SD_MAX_GROUPS 32
 struct RowTab {
@@ -46,7 +47,7 @@ struct RowTab {
     // is set in tree_mask[m] (its ancestors and itself).  row_pos[] then carries the RoPE / learned position of the
     // node (its depth), while its K / V rows go to the arena slot tree_base + m.
     int tree, tree_base;
-    unsigned long long tree_mask[SD_MAX_ROWS];
+    unsigned long long tree_mask[SD_MAX_TREE];
     int kv_fp8;                                     // the arenas hold OCP fp8 e4m3 (1 byte per element) instead of T
     const float *kv_scale[SD_MAX_STREAMS];          // fp8: per (layer, k|v, kv head) scales [L][2][Hkv], x = fp8 * scale
     // attention groups: <= ATT_TQ consecutive rows of one stream (first row, count, position of the first row, stream)
@@ -153,6 +154,7 @@ struct GemmEpiT {
     RowTab tab;
 };
 using GemmEpi = GemmEpiT<bf16_t>;
+static_assert(sizeof(GemmEpiT<bf16_t>) <= 3072, "GemmEpiT travels by value in the kernel arguments (4 KiB in all)");
 
 template <typename H>
 __device__ __forceinline__ void store4(H *dst, float a, float b, float c, float d) {
@@ -1013,7 +1015,7 @@ __device__ __forceinline__ void attn_body(const T *__restrict__ qbuf, const RowT
     auto vis = [&](int t, int s) -> bool {                        // may row t of the group see local key s?
         if (!tree) return s <= vis0 + t;
         const int g = s + kb - tab.tree_base;                     // index among the tree rows (< 0: a cached key)
-        return g < 0 || ((tab.tree_mask[min(r0 + t, SD_MAX_ROWS - 1)] >> g) & 1ull);
+        return g < 0 || ((tab.tree_mask[min(r0 + t, SD_MAX_TREE - 1)] >> g) & 1ull);
     };
     // (an empty chunk - split attention past the visible keys - reads from the head's first key: loads are never branched
     //  around, see below, so their addresses must be valid)

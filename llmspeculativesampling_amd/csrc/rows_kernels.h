@@ -1,4 +1,4 @@
-// Weight-streaming GEMM for 17..64 activation rows (stream-batched verify, SURVEY.md 8(f) rank 1: B streams x (gamma+1) rows
+// Weight-streaming GEMM for 17..80 activation rows (stream-batched verify, SURVEY.md 8(f) rank 1: B streams x (gamma+1) rows
 // share one pass over the target's weights; lifts the batch-1 limit of reference speculative_sampling.py:1905).
 //
 //     part[sb][m][n] = sum_{k in slab sb} X[m][k] * W[n][k]        (or the fused QKV / activation epilogue when SB == 1)
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     } else {
         for (int c = 0; c < nch; ++c) bar();                      // idle wave: keeps the barrier count
     }
-    // ---- fold the k-groups' accumulators through LDS (slots past nwk hold zeros), then the epilogue: thread group
-    // tid / 256 takes tile t0 + tid / 256 (+ 4 in the second round) exactly as a streaming-kernel workgroup would
+    // ---- fold the k-groups' accumulators through LDS (slots past nwk hold zeros), then the epilogue: the workgroup's threads
+    // are dealt (tile, m-tile, lane) items - EL per tile - and each runs the streaming kernel's epilogue code for its item
     if (probe & 16) { if (acc[0][0] == 123.456f) part[0] = 1.f; return; }
     __syncthreads();
     if (comp) {
@@ -153,10 +153,9 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int g4 = (int)(threadIdx.x >> 8) + 4 * j, tile = t0 + g4;
-        if (g4 < nwn && tile < t1)
-            gemm_epilogue_step<MT, EPI, 1, MT, H>(red[g4], 0, part, M, Mpad, N, sb, tile, e, (int)(threadIdx.x & 255));
+    constexpr int EL = (EPI == EPI_ACT_SILU ? 32 : 64) * MT;      // threads one tile's epilogue takes (SiLU pairs gate / up lanes)
+    for (int i = (int)threadIdx.x; i < nwn * EL; i += GR_THREADS) {
+        const int g4 = i / EL, tile = t0 + g4;
+        if (tile < t1) gemm_epilogue_step<MT, EPI, 1, MT, H>(red[g4], 0, part, M, Mpad, N, sb, tile, e, i - g4 * EL);
     }
 }

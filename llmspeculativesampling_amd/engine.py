@@ -20,7 +20,8 @@ from . import _lib
 from ._lib import lib, check
 from .config import ModelConfig, config_from_hf
 
-MAX_ROWS_PER_FORWARD = 64       # rows of one stream-batched pass, and logit rows of any one call
+MAX_ROWS_PER_FORWARD = 80       # rows of one stream-batched pass (SD_MAX_ROWS: 8 streams x (gamma + 1 = 9) verify rows = 72)
+MAX_LOGIT_ROWS = 64             # logit rows of one single-sequence call (the lm_head's row gather: streaming kernel), tree nodes
 MAX_PREFILL_ROWS = 256          # rows of one single-sequence sd_session_forward call; longer prompts are chunked
 
 
@@ -381,8 +382,8 @@ class Session:
         while done < n:
             m = min(self.max_rows, n - done)
             lo = max(first_logit_row, done)            # rows of this chunk that need logits (at most 64 per call)
-            if done + m - lo > MAX_ROWS_PER_FORWARD:
-                m = lo + MAX_ROWS_PER_FORWARD - done
+            if done + m - lo > MAX_LOGIT_ROWS:
+                m = lo + MAX_LOGIT_ROWS - done
             nl = max(0, done + m - lo)
             dst = logits_out.data_ptr() + (lo - first_logit_row) * ld * 4 if nl else None
             check(lib.sd_session_forward(self.handle, tokens.data_ptr() + done * 4, m, pos0 + done, nl, dst, ld, st),

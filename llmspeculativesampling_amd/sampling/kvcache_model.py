@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 
 from .._lib import lib, check, SdNormRow
-from ..engine import batch_forward, SpecDecModel, Session, as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, check_token_ids
+from ..engine import batch_forward, SpecDecModel, Session, as_specdec_model, _stream, MAX_ROWS_PER_FORWARD, MAX_LOGIT_ROWS, check_token_ids
 from ..noise import HostTorchNoise
 
 
@@ -101,7 +101,7 @@ class KVCacheModel:
             ev0.record()
         while done < n_rows_out:                        # logits buffer holds max_rows rows at a time
             # feed everything up to the end of this block of output rows
-            blk = min(MAX_ROWS_PER_FORWARD, n_rows_out - done)
+            blk = min(MAX_LOGIT_ROWS, n_rows_out - done)
             end = first + done + blk
             logits = ses.forward(seq32[ses.cache_len:end], blk)
             t1 = process_time_ns()
@@ -332,8 +332,8 @@ class KVCacheModel:
         m = self._model
         V, dev = m.cfg.vocab_size, m.device
         P, N = int(prefix.size(-1)), int(input_ids.size(1))
-        if N > MAX_ROWS_PER_FORWARD:
-            raise ValueError(f"a tree of {N} nodes exceeds one verify pass ({MAX_ROWS_PER_FORWARD} rows)")
+        if N > MAX_LOGIT_ROWS:
+            raise ValueError(f"a tree of {N} nodes exceeds one verify pass ({MAX_LOGIT_ROWS} rows)")
         self._ensure(P + N + 1)
         ses = self._session
         cached = ses.cache_len

@@ -14,7 +14,7 @@ print("bench: value", d["value"], "ms/step", d["ms_per_step"], "roofline", d["ro
 print({k: v for k, v in d.items() if "ms" in k and not isinstance(v, (dict, list))})
 PY
 ;;
-b8) timeout -k 10 300 python bench.py --steps 1 --warmup 1 --cpu-baseline 0 --accept-sweep 0 --batch-streams 8 > $O/bench_b8.json 2>$O/bench_b8.err; python - <<PY
+b8) timeout -k 10 300 python bench.py --steps 1 --warmup 1 --cpu-baseline 0 --accept-sweep 0 --batch-streams 8 $B8_EXTRA > $O/bench_b8.json 2>$O/bench_b8.err; python - <<PY
 import json
 d=json.loads([l for l in open("$O/bench_b8.json") if l.startswith("{")][0])
 print("b8: value", d["value"], "roofline", d["roofline"])
