@@ -42,6 +42,11 @@ def parse(argv=None):
     ap.add_argument("--target", default="llama-2-13b")
     ap.add_argument("--gamma", type=int, default=4)
     ap.add_argument("--prompt-len", type=int, default=128)
+    ap.add_argument("--prompt-lens", default="fixed", choices=["fixed", "synthetic-c3"],
+                    help="fixed: every stream's prompt has --prompt-len tokens (BASELINE configs[1], [3]); synthetic-c3: "
+                         "SURVEY.md 8(d) C3's fallback inputs for configs[2] when chatalpaca is not on disk - 100 synthetic "
+                         "prompts with lengths U{32..512}, seed 5 (harness.synthetic_prompts, reference evaluation.py:347-364 "
+                         "reads the real set); stream s takes prompt s mod 100")
     ap.add_argument("--max-len", type=int, default=128)
     ap.add_argument("--top-k", type=int, default=20)
     ap.add_argument("--top-p", type=float, default=0.9)
@@ -332,7 +337,15 @@ def main(argv=None):
     from llmspeculativesampling_amd.sampling import speculative_sampling, speculative_sampling_batch
 
     dcfg, tcfg = load_config(args.draft), load_config(args.target)
-    max_pos = args.prompt_len + args.max_len + args.gamma + 8
+    c3_prompts = None
+    if args.prompt_lens == "synthetic-c3":
+        from llmspeculativesampling_amd.harness import synthetic_prompts
+        c3_prompts = synthetic_prompts(100, tcfg.vocab_size, seed=5)
+    max_plen = max(int(p.shape[1]) for p in c3_prompts) if c3_prompts else args.prompt_len
+    max_pos = max_plen + args.max_len + args.gamma + 8
+
+    def prompt_of(stream):
+        return c3_prompts[stream % len(c3_prompts)] if c3_prompts else prompt_for(stream, tcfg.vocab_size, args.prompt_len)
     t0 = time.time()
     TP = args.tp
     # real checkpoints from a LOCAL directory when SPECDEC_MODEL_DIR holds them (never the hub), else
@@ -375,15 +388,15 @@ def main(argv=None):
 
     def run_step(stream, logs=None):
         if BS > 1:
-            prompts = [prompt_for(stream * BS + j, tcfg.vocab_size, args.prompt_len).cuda() for j in range(BS)]
+            prompts = [prompt_of(stream * BS + j).cuda() for j in range(BS)]
             outs, ds = speculative_sampling_batch(prompts, dm, tm, eos_token_id=2, pad_token_id=None, max_len=args.max_len,
                                                   gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True,
                                                   seeds=[2000 + stream * BS + j for j in range(BS)],
                                                   _timing=logs if isinstance(logs, dict) else None)
             d = {"acc_len": [a for x in ds for a in x["acc_len"]], "target_call_times": sum(x["target_call_times"] for x in ds)}
-            new = sum(int(o.shape[1]) - args.prompt_len for o in outs)
+            new = sum(int(o.shape[1]) - int(p.shape[1]) for o, p in zip(outs, prompts))
             return outs, d, new
-        prompt = prompt_for(stream, tcfg.vocab_size, args.prompt_len).cuda()
+        prompt = prompt_of(stream).cuda()
         if args.rng == "device":
             nz = DeviceNoise(seed=2000 + stream)
         else:
@@ -392,7 +405,7 @@ def main(argv=None):
         out, d = speculative_sampling(prompt, dm, tm, eos_token_id=2, pad_token_id=None, max_len=args.max_len,
                                       gamma=args.gamma, top_k=args.top_k, top_p=args.top_p, details=True, rng=nz,
                                       _event_logs=logs)
-        return [out], d, int(out.shape[1]) - args.prompt_len
+        return [out], d, int(out.shape[1]) - int(prompt.shape[1])
 
     # streams: rank r takes s = r, r+world, ... (round-robin)
     srank, sworld = (0, 1) if TP > 1 else (rank, world)      # tensor parallel: one stream per step for the whole group
@@ -412,7 +425,7 @@ def main(argv=None):
     if dist is not None and TP == 1:
         # throughput-mode gather of the generated ids (KB-scale; the only collective on the path)
         from llmspeculativesampling_amd.dist import gather_streams
-        width = args.prompt_len + args.max_len + args.gamma + 1
+        width = max_plen + args.max_len + args.gamma + 1
         all_streams = gather_streams(outs, args.steps * world * BS, width, device=comm_dev)
         assert len(all_streams) == args.steps * world * BS
     barrier()
@@ -453,7 +466,7 @@ def main(argv=None):
                 ver_S.append(upto)
         drf_ms = [e0.elapsed_time(e1) for (e0, e1, n_new, _) in logs[0] if n_new <= 2]
     t_ver = float(np.mean(ver_ms)) if ver_ms else float("nan")
-    S_mean = float(np.mean(ver_S)) if ver_S else float(args.prompt_len + args.max_len / 2)
+    S_mean = float(np.mean(ver_S)) if ver_S else float(max_plen + args.max_len / 2)
     b_ver = algorithmic_verify_bytes(tm.cfg if TP > 1 else tcfg, args.gamma, S_mean, kvbytes=1 if args.kv_dtype == "fp8" else 2)
     if BS > 1:       # one pass over the weights serves BS streams; KV and logits scale with the stream count
         w_only = tcfg.n_params(streamed_only=True) * 2
@@ -518,7 +531,8 @@ def main(argv=None):
         "vs_baseline": None, "dtype": "bf16",
         "data": "checkpoint" if use_ckpt else "synthetic", "scaling_note": None if TP == 1 else
         "tensor-parallel target: the ranks decode the SAME stream together (strong scaling of one stream), per-rank roofline",
-        "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt {args.prompt_len}, "
+        "config": {"workload": f"{args.draft} -> {args.target}, gamma={args.gamma}, bf16, prompt " +
+                               (f"{args.prompt_len}" if not c3_prompts else "lengths U{32..512} (100 synthetic prompts, seed 5: SURVEY 8(d) C3)") + ", "
                                f"max_len {args.max_len}, top_k {args.top_k}, top_p {args.top_p}, {BS} stream(s) per step per GPU"
                                f"{' decoded in lockstep through shared weight passes' if BS > 1 else ''}, "
                                f"rng={args.rng}; " + (f"local checkpoints {ckpt_d} -> {ckpt_t}, synthetic prompts" if use_ckpt else

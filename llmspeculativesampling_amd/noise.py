@@ -74,6 +74,14 @@ class HostTorchNoise:
         r = torch.cat([torch.rand(1, generator=self.gen) for _ in range(gamma)])
         return r.to(self.device), state
 
+    def uniform_one(self) -> torch.Tensor:
+        """One ``torch.rand(1)`` (the beam variant draws its uniforms one at a time, speculative_sampling.py:288)."""
+        return torch.rand(1, generator=self.gen)
+
+    def uniform64_one(self) -> torch.Tensor:
+        """One double uniform: ATen's with-replacement multinomial draws one per sample (sampling/beam.py)."""
+        return torch.rand(1, dtype=torch.float64, generator=self.gen)
+
     def realign(self, token, consumed: int) -> None:
         """The reference stops drawing at the first reject: rewind and draw exactly `consumed`."""
         if token is None:
@@ -132,6 +140,12 @@ class ReplayNoise:
     def skip_exponential_rows(self, rows: int, V: int, dtype=None) -> None:
         e = torch.as_tensor(self._take("exp"))
         assert e.numel() == rows * V
+
+    def uniform_one(self) -> torch.Tensor:
+        return torch.as_tensor(self._take("uni"), dtype=torch.float32).reshape(1)
+
+    def uniform64_one(self) -> torch.Tensor:
+        return torch.as_tensor(self._take("uni64"), dtype=torch.float64).reshape(1)
 
     def uniforms(self, gamma: int, random_seed):
         # the recording holds only the uniforms the reference actually consumed (it stops at the first

@@ -366,9 +366,12 @@ class KVCacheModel:
         gather_pos[:, 1] += P
         return self._probs[gather_pos[:, 1].to(dev)].to(m.probs_dtype)
 
-    def beam_rollback(self, *a, **k):
-        raise NotImplementedError("beam rollback (reference kvcache_model.py:312-324) serves beam_sample_with_kv_cache, "
-                                  "whose transformers 4.35 BeamSearchScorer dependency is not available (DESIGN.md 8)")
+    def beam_rollback(self, beam_idx, choice):
+        """reference kvcache_model.py:312-324 (parity unpinned, see sampling/beam.py): the draft's cache as it was after
+        beam step `beam_idx`, of beam `choice` only."""
+        if getattr(self, "_beam", None) is None:
+            raise RuntimeError("beam_rollback before beam_sample_with_kv_cache")
+        self._beam.beam_rollback(int(beam_idx), int(choice))
 
     @torch.no_grad()
     def rollback_tree_attention(self, input_idx: torch.Tensor, mask: torch.Tensor):
@@ -393,8 +396,13 @@ class KVCacheModel:
         ses.cache_len = P + len(idx)
         self._hist_len = P + len(idx)
 
-    def beam_sample_with_kv_cache(self, *a, **k):
-        raise NotImplementedError("beam sampling (reference kvcache_model.py:439-567) is out of scope")
+    def beam_sample_with_kv_cache(self, prefix, gamma, num_beams, top_k=None, top_p=None, **kwargs):
+        """reference kvcache_model.py:439-567 -> :571-1025, decoder-only, return_intermediate_results=True,
+        optimization=False (the driver's only use, speculative_sampling.py:84-98): `gamma` steps of beam sampling over
+        `num_beams` KV arenas of this model.  Parity unpinned (sampling/beam.py)."""
+        from .beam import kv_beam_sample_with_kv_cache
+        return kv_beam_sample_with_kv_cache(self, prefix, gamma, num_beams, top_k=top_k, top_p=top_p, **kwargs)
 
     def beam_sample(self, *a, **k):
-        raise NotImplementedError("beam sampling (reference kvcache_model.py:571-1025) is out of scope")
+        raise NotImplementedError("call beam_sample_with_kv_cache (reference kvcache_model.py:439-567): beam_sample's "
+                                  "own arguments are transformers 4.35 objects (BeamScorer, LogitsProcessorList)")

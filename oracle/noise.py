@@ -26,6 +26,10 @@ class TorchGlobalNoise:
     def uniform(self) -> torch.Tensor:
         return torch.rand(1)
 
+    def uniform64(self) -> torch.Tensor:
+        """One double uniform: what ATen's with-replacement multinomial draws per sample (oracle/beam_ref.py)."""
+        return torch.rand(1, dtype=torch.float64)
+
     def reseed(self, seed: int) -> None:
         torch.manual_seed(seed)
 
@@ -45,6 +49,11 @@ class RecordingNoise:
     def uniform(self):
         r = self.inner.uniform()
         self.events.append(("uni", r.clone()))
+        return r
+
+    def uniform64(self):
+        r = self.inner.uniform64()
+        self.events.append(("uni64", r.clone()))
         return r
 
     def reseed(self, seed):
@@ -76,6 +85,9 @@ class RecordedNoise:
 
     def uniform(self):
         return torch.as_tensor(self._next("uni"), dtype=torch.float32).reshape(1)
+
+    def uniform64(self):
+        return torch.as_tensor(self._next("uni64"), dtype=torch.float64).reshape(1)
 
     def reseed(self, seed):
         s = self._next("seed")

@@ -1100,3 +1100,46 @@ def test_norm_on_load_seams_with_rows_of_two_streams(hip):
     assert float((got - want).abs().max()) <= 0.03 * float(want.abs().max())
     for a, b, L, n in zip(solo, both, lens, new):
         assert torch.equal(a.kv[0, :, :, :L + n], b.kv[0, :, :, :L + n])
+
+
+# --------------------------------------------------------------------------- (f)4: the beam variant end to end (parity unpinned)
+@pytest.mark.parametrize("arch,nb,thres,seed", [("llama", 3, 0.7, 0), ("llama", 2, 0.5, 1), ("llama", 5, 0.9, 2), ("opt", 4, 0.7, 3)])
+def test_beam_speculative_sampling_v2_vs_oracle(hip, arch, nb, thres, seed):
+    """beam_speculative_sampling_v2 (reference speculative_sampling.py:18-581, extra_sample_cnt == 1) on the engine - the
+    draft's num_beams KV arenas sharing one weight pass per beam step, the reorder / per-step snapshots on the few rows
+    that differ, the tree verify and the path compaction - against oracle.beam_ref's restatement fed the SAME variates
+    (recorded from the oracle's run, replayed into the device path): tokens, accepted lengths, accepted-beam counts,
+    expected counts and call counts must be identical, with accepted, rejected and all-accepted levels in the run, and
+    with an EOS stop.  The draft side of this variant is PARITY UNPINNED (sampling/beam.py, oracle/beam_ref.py: the
+    reference's own beam path needs transformers 4.35's BeamSearchScorer, absent here); its target side is pinned by G9."""
+    from oracle import beam_ref
+    from llmspeculativesampling_amd.noise import ReplayNoise
+    if arch == "llama":
+        dc, dsd, tc, tsd = _pair("corr", seed=11 + seed)
+    else:
+        dc, dsd, tc, tsd = _pair("opt", seed=11 + seed)
+    V = dc.vocab_size
+    prompt = torch.from_numpy(np.random.default_rng(60 + seed).integers(3, V, size=(1, 9)))
+    kw = dict(gamma=4, width=nb, num_beams=nb, extra_sample_cnt=1, expect_thres=thres, top_k=20, top_p=0.9, details=True)
+    od, ot = oracle.RefCausalLM(dc, dsd), oracle.RefCausalLM(tc, tsd)
+    torch.manual_seed(seed)
+    probe, _ = beam_ref.beam_speculative_sampling_v2(prompt, od, ot, -1, None, 20, **kw)
+    dm = hip.engine.SpecDecModel.from_state_dict(dc, dsd, dtype=torch.float32)
+    tm = hip.engine.SpecDecModel.from_state_dict(tc, tsd, dtype=torch.float32)
+    for eos in (-1, int(probe[0, 9 + 12])):
+        rec = oracle.RecordingNoise()
+        torch.manual_seed(seed)
+        want, wd = beam_ref.beam_speculative_sampling_v2(prompt, od, ot, eos, None, 20, noise=rec, **kw)
+        got, gd = hip.S.beam_speculative_sampling_v2(prompt.cuda(), dm, tm, eos, None, 20, rng=ReplayNoise(rec.events, "cuda"), **kw)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.numpy())
+        for key in ("acc_len", "num_beams_list", "expect_cnt_list", "target_call_times", "approx_call_times"):
+            assert gd[key] == wd[key], key
+        assert abs(float(gd["acc_rate"]) - float(wd["acc_rate"])) < 1e-6
+        if eos >= 0:
+            assert int(want[0, -1]) == eos and want.shape[1] < 9 + 20
+        elif arch == "llama":                                    # (the OPT pair is unrelated models: hardly any accept)
+            assert 0 < sum(wd["acc_len"]) < 4 * len(wd["acc_len"])
+    # device Philox draws: same loop, no host noise; the run must be well-formed and reproducible
+    a, ad = hip.S.beam_speculative_sampling_v2(prompt.cuda(), dm, tm, -1, None, 20, rng=hip.noise.DeviceNoise(5), **kw)
+    b, _ = hip.S.beam_speculative_sampling_v2(prompt.cuda(), dm, tm, -1, None, 20, rng=hip.noise.DeviceNoise(5), **kw)
+    assert torch.equal(a, b) and a.shape[1] == 9 + sum(x + 1 for x in ad["acc_len"]) >= 9 + 20

@@ -285,9 +285,11 @@ def test_sampling_package_exports_every_reference_name():
     for n in ref_all:
         assert callable(getattr(S, n)) and n in S.__all__
     for n in ("speculative_sampling_v2", "beam_speculative_sampling", "BiLD_sampling", "mjsd_speculative_sampling",
-              "random_width_beam_sampling", "beam_speculative_sampling_v2"):
+              "random_width_beam_sampling"):
         with pytest.raises(NotImplementedError):
             getattr(S, n)(None, None, None)
+    with pytest.raises(NotImplementedError, match="extra_sample_cnt"):           # built for one input sequence per verify
+        S.beam_speculative_sampling_v2(None, None, None, 2, None, 8, num_beams=4, extra_sample_cnt=2)
 
 
 # --------------------------------------------------------------------------- bench.py launcher
