@@ -146,10 +146,12 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // 8 k-steps (8 KiB of weights) per workgroup.
 // Environment tunables, sampled when a session (or a spec handle) is created and by the public one-off GEMM entries - not
 // per launch: a draft step is ~40 getenv() scans otherwise, on the host thread that has to keep the GPU fed.
+#define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
+#define SD_ROWS_MAX 128                              // rows the balanced one-workgroup-per-CU kernel covers (8 m-tiles)
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2;
+    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -168,6 +170,7 @@ static void refresh_env() {
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
+    g_env.rows_max = std::min(SD_ROWS_MAX, std::max(SD_STREAM_MAX_ROWS, geti("SD_GEMM_ROWS_MAX", SD_ROWS_MAX)));   // 65..this many rows take the balanced kernel, more the LDS-tiled one
     if (!g_env.cus) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -239,7 +242,6 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
 struct GemmPlan { bool tiled; int S, ksp, mtw; };
 struct RowsPlan { bool ok; int S, ksp, NG, grid, nwn, nwk, nld; };
 static RowsPlan rows_plan(int N, int K, int M, bool fused);
-#define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
 // fused: the caller wants the GEMM's whole k-range per workgroup (QKV / activation epilogue inside the launch)
 static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused = false) {
     GemmPlan p = {};
@@ -247,7 +249,7 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
     static const int tiled_min = getenv("SD_GEMM_TILED_MIN") ? atoi(getenv("SD_GEMM_TILED_MIN")) : 65;
     // (65..SD_MAX_ROWS rows - 8 streams x 9 verify rows - stay on the balanced one-workgroup-per-CU kernel, with its fused
     //  epilogues, when both of its plans for the shape are good; prefill chunks of that size take it too)
-    const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= SD_MAX_ROWS && rows_plan(N, K, M, fused).ok;
+    const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= g_env.rows_max && rows_plan(N, K, M, fused).ok;
     if (x_tiled && M >= tiled_min && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
         p.tiled = true;
         p.mtw = Mpad <= 64 ? 2 : 4;
@@ -288,7 +290,7 @@ static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, 
 // CU; a fused epilogue needs S == 1.  The plan minimises (weight bytes + slab traffic) / how evenly the n-tiles divide.
 static RowsPlan rows_plan(int N, int K, int M, bool fused) {
     RowsPlan p = {};
-    if (!g_env.gemm_rows || M <= 16 || M > SD_MAX_ROWS || N % 16 || K % 32) return p;
+    if (!g_env.gemm_rows || M <= 16 || M > SD_ROWS_MAX || N % 16 || K % 32) return p;
     const int G = g_env.cus > 0 ? g_env.cus : 256, NT = N / 16, KS = K / 32, Mpad = (int)align_up(M, 16);
     const double wbytes = (double)N * K * 2.0, slab = 2.0 * Mpad * (double)N * 4.0;
     double best = 1e300;
@@ -312,6 +314,7 @@ static RowsPlan rows_plan(int N, int K, int M, bool fused) {
         p.nwn = (NT + p.NG - 1) / p.NG;
         p.nwk = std::min(4, (16 - 1) / p.nwn);
         if (Mpad > 64) p.nwk = std::min(p.nwk, 3);                 // (5 m-tiles: 2 x 4 k-groups x 4 k-steps x 5 KiB exceed the CU's LDS)
+        if (Mpad > 80) p.nwk = std::min(p.nwk, 2);                 // (8 m-tiles: 2 x 2 x 4 x 8 KiB = 128 KiB is what fits)
         p.nld = std::min(p.nwk, 16 - p.nwn * p.nwk);
     }
     return p;
@@ -320,37 +323,44 @@ static RowsPlan rows_plan(int N, int K, int M, bool fused) {
 template <int EPI, typename H>
 static int launch_gemm_rows(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, const RowsPlan &pl,
                             const GemmEpiT<H> &e, hipStream_t st) {
-    const int MT = Mpad / 16;
-    // activation panel (2 buffers x nwk k-groups x CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x 4 x MT);
-    // chunks of 8 k-steps where the panel fits the CU's LDS (one workgroup per CU owns all of it), else 4
+    // m-tiles of the kernel instance: 2..5 as they are, 6..8 all take the 8-tile instance (the loader re-reads the last
+    // real tile for the missing ones, the epilogue drops rows >= M)
+    const int MT = Mpad / 16 <= 5 ? Mpad / 16 : 8;
+    // activation panel (2 buffers x nwk k-groups x CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x nwk x
+    // MT); chunks of 8 k-steps where the panel fits the CU's LDS (one workgroup per CU owns all of it), else 6 or 4 -
+    // with chunks of 4 a compute wave's weight burst spans two chunks (8 KiB requested together: WBM = 2)
     constexpr size_t lds_cap = 158 * 1024;
     int ch = 4;
     for (int c2 : {8, 6})
         if ((size_t)1024 * MT * 2 * pl.nwk * c2 <= lds_cap) { ch = c2; break; }
     if (MT == 2) ch = 8;                                          // (2 x 4 x 8 x 2 KiB always fits)
     if (MT == 3 && ch == 4) ch = 6;                               // (2 x 4 x 6 x 3 KiB = 144 KiB: the widest 3-tile panel)
-    const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * ch, 4 * pl.nwn);
-    SD_REQUIRE(lds <= lds_cap, "gemm_rows: %zu bytes of LDS", lds);
-    auto go = [&](auto mt_c, auto ch_c) {
-        constexpr int MTc = decltype(mt_c)::value, CHc = decltype(ch_c)::value;
+    const size_t lds = (size_t)1024 * MT * std::max(2 * pl.nwk * ch, pl.nwk * pl.nwn);
+    SD_REQUIRE(lds <= lds_cap && Mpad / 16 <= MT, "gemm_rows: %d rows, %zu bytes of LDS", M, lds);
+    auto go = [&](auto mt_c, auto ch_c, auto wbm_c) {
+        constexpr int MTc = decltype(mt_c)::value, CHc = decltype(ch_c)::value, WBMc = decltype(wbm_c)::value;
         static bool attr = false;                                 // (one flag per instantiation)
         if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H, CHc>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16_rows<MTc, EPI, H, CHc, WBMc>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
             attr = true;
         }
-        hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H, CHc>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
+        hipLaunchKernelGGL((gemm_bf16_rows<MTc, EPI, H, CHc, WBMc>), dim3(pl.grid), dim3(GR_THREADS), lds, st, (const u32x4 *)W,
                            (const u32x4 *)X, part, M, Mpad, N, K, pl.NG, pl.ksp, pl.nwn, pl.nwk, pl.nld, e);
     };
     using std::integral_constant;
-    if (MT == 2) go(integral_constant<int, 2>{}, integral_constant<int, 8>{});
-    else if (MT == 3) { if (ch == 8) go(integral_constant<int, 3>{}, integral_constant<int, 8>{}); else go(integral_constant<int, 3>{}, integral_constant<int, 6>{}); }
-    else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{});
-                        else if (ch == 6) go(integral_constant<int, 4>{}, integral_constant<int, 6>{});
-                        else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}); }
-    else if (MT == 5) { if (ch == 6) go(integral_constant<int, 5>{}, integral_constant<int, 6>{});       // (8 never fits at 5 m-tiles)
-                        else go(integral_constant<int, 5>{}, integral_constant<int, 4>{}); }
-    else { sd_set_error("gemm_rows: %d rows", M); return SD_ERR_INVALID; }
+    using I1 = integral_constant<int, 1>;
+    using I2 = integral_constant<int, 2>;
+    if (MT == 2) go(integral_constant<int, 2>{}, integral_constant<int, 8>{}, I1{});
+    else if (MT == 3) { if (ch == 8) go(integral_constant<int, 3>{}, integral_constant<int, 8>{}, I1{});
+                        else go(integral_constant<int, 3>{}, integral_constant<int, 6>{}, I1{}); }
+    else if (MT == 4) { if (ch == 8) go(integral_constant<int, 4>{}, integral_constant<int, 8>{}, I1{});
+                        else if (ch == 6) go(integral_constant<int, 4>{}, integral_constant<int, 6>{}, I1{});
+                        else go(integral_constant<int, 4>{}, integral_constant<int, 4>{}, I2{}); }
+    else if (MT == 5) { if (ch == 6) go(integral_constant<int, 5>{}, integral_constant<int, 6>{}, I1{});       // (8 never fits at 5 m-tiles)
+                        else go(integral_constant<int, 5>{}, integral_constant<int, 4>{}, I2{}); }
+    else if (MT == 8 && ch == 4) go(integral_constant<int, 8>{}, integral_constant<int, 4>{}, I2{});
+    else { sd_set_error("gemm_rows: %d rows (chunk %d)", M, ch); return SD_ERR_INVALID; }
     return SD_OK;
 }
 

@@ -189,14 +189,14 @@ __device__ __forceinline__ void store4_maybe_wt(H *dst, float a, float b, float 
 // folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
 // gemm_small (small_kernels.h).
 // E: GemmEpiT<H>, or any view with the same member names.
-template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false>
-__device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
+// gemm_epilogue_fold: the epilogue proper, on any source of folded sums - `folded(pp, l)` returns lane l's f32x4 of
+// accumulator tile pp with the k-split already added up; gemm_epilogue_step (below) is the form of the kernels whose four
+// waves leave their accumulators in red[wave][pp][lane].
+template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false, typename FoldFn>
+__device__ __forceinline__ void gemm_epilogue_fold(FoldFn folded, int fs, float *__restrict__ part, int M, int Mpad,
                                                    int N, int sb, int ntg, const E &e, int tid_ = -1) {
-    // tid_: the calling wave's threads counted from 0 (the engine's epilogue wave is not the workgroup's first)
+    // tid_: the calling wave's threads counted from 0 (a caller whose epilogue threads are not the workgroup's first)
     const int tidx = tid_ >= 0 ? tid_ : (int)threadIdx.x;
-    auto folded = [&](int pp, int l) -> f32x4 {
-        return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
-    };
     if constexpr (EPI == EPI_PART) {
         if (tidx < PT * 64) {
             const int pp = tidx >> 6, l = tidx & 63, q = fs * PT + pp;
@@ -293,6 +293,15 @@ __device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs,
             }
         }
     }
+}
+
+template <int MT, int EPI, int NTW, int PT, typename H = bf16_t, typename E = GemmEpiT<H>, bool WT = false>
+__device__ __forceinline__ void gemm_epilogue_step(f32x4 (*red)[PT][64], int fs, float *__restrict__ part, int M, int Mpad,
+                                                   int N, int sb, int ntg, const E &e, int tid_ = -1) {
+    auto folded = [&](int pp, int l) -> f32x4 {
+        return (red[0][pp][l] + red[1][pp][l]) + (red[2][pp][l] + red[3][pp][l]);
+    };
+    gemm_epilogue_fold<MT, EPI, NTW, PT, H, E, WT>(folded, fs, part, M, Mpad, N, sb, ntg, e, tid_);
 }
 
 // Residual epilogue of a GEMM whose workgroup holds the COMPLETE sums of one 16-column tile for <= 16 rows (k-split folded
