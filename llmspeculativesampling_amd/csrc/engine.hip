@@ -147,7 +147,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 // Environment tunables, sampled when a session (or a spec handle) is created and by the public one-off GEMM entries - not
 // per launch: a draft step is ~40 getenv() scans otherwise, on the host thread that has to keep the GPU fed.
 #define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
-#define SD_ROWS_MAX 128                              // rows the balanced one-workgroup-per-CU kernel covers (8 m-tiles)
+#define SD_ROWS_MAX 144                              // rows the balanced one-workgroup-per-CU kernel covers (9 m-tiles: a 128-token prompt + gamma rows)
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
@@ -314,7 +314,7 @@ static RowsPlan rows_plan(int N, int K, int M, bool fused) {
         p.nwn = (NT + p.NG - 1) / p.NG;
         p.nwk = std::min(4, (16 - 1) / p.nwn);
         if (Mpad > 64) p.nwk = std::min(p.nwk, 3);                 // (5 m-tiles: 2 x 4 k-groups x 4 k-steps x 5 KiB exceed the CU's LDS)
-        if (Mpad > 80) p.nwk = std::min(p.nwk, 2);                 // (8 m-tiles: 2 x 2 x 4 x 8 KiB = 128 KiB is what fits)
+        if (Mpad > 80) p.nwk = std::min(p.nwk, 2);                 // (8 / 9 m-tiles: 2 x 2 x 4 x 8 KiB = 128 KiB, x 9 = 144 KiB, is what fits)
         p.nld = std::min(p.nwk, 16 - p.nwn * p.nwk);
     }
     return p;
@@ -325,7 +325,7 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
                             const GemmEpiT<H> &e, hipStream_t st) {
     // m-tiles of the kernel instance: 2..5 as they are, 6..8 all take the 8-tile instance (the loader re-reads the last
     // real tile for the missing ones, the epilogue drops rows >= M)
-    const int MT = Mpad / 16 <= 5 ? Mpad / 16 : 8;
+    const int MT = Mpad / 16 <= 5 ? Mpad / 16 : (Mpad / 16 <= 8 ? 8 : 9);
     // activation panel (2 buffers x nwk k-groups x CH k-steps x MT tiles), reused as the fold buffer (nwn tiles x nwk x
     // MT); chunks of 8 k-steps where the panel fits the CU's LDS (one workgroup per CU owns all of it), else 6 or 4 -
     // with chunks of 4 a compute wave's weight burst spans two chunks (8 KiB requested together: WBM = 2)
@@ -360,6 +360,7 @@ static int launch_gemm_rows(const void *W, const void *X, float *part, int M, in
     else if (MT == 5) { if (ch == 6) go(integral_constant<int, 5>{}, integral_constant<int, 6>{}, I1{});       // (8 never fits at 5 m-tiles)
                         else go(integral_constant<int, 5>{}, integral_constant<int, 4>{}, I2{}); }
     else if (MT == 8 && ch == 4) go(integral_constant<int, 8>{}, integral_constant<int, 4>{}, I2{});
+    else if (MT == 9 && ch == 4) go(integral_constant<int, 9>{}, integral_constant<int, 4>{}, I2{});
     else { sd_set_error("gemm_rows: %d rows (chunk %d)", M, ch); return SD_ERR_INVALID; }
     return SD_OK;
 }

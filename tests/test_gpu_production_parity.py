@@ -160,7 +160,7 @@ def test_mfma_gemm_is_integer_exact_at_production_shapes(hip, shape):
     assert hip.lib.sd_pack_weight_bf16(W.data_ptr(), Wp.data_ptr(), N, K, _st()) == 0
     Wf = W.double()
     part = torch.empty(64 * 64 * N if N <= 8192 else 20 * 256 * N, dtype=torch.float32, device="cuda")
-    for M in (1, 5, 16, 17, 40, 60, 64, 72, 80, 96, 127, 128, 256):
+    for M in (1, 5, 16, 17, 40, 60, 64, 72, 80, 96, 127, 128, 132, 144, 256):
         X = torch.randint(-4, 5, (M, K), device="cuda", generator=g).to(torch.bfloat16)
         Xt = torch.zeros((M + 15) // 16 * 16 * K, device="cuda", dtype=torch.bfloat16)
         assert hip.lib.sd_pack_activation_bf16(X.data_ptr(), Xt.data_ptr(), M, K, _st()) == 0
