@@ -151,7 +151,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
+    int tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -170,6 +170,7 @@ static void refresh_env() {
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
+    g_env.tp_one_slab = geti("SD_TP_ONE_SLAB", 1);    // 0: a shard's O / down projection keeps its k-slabs + the fold launch in front of the all-reduce (A/B)
     g_env.rows_max = std::min(SD_ROWS_MAX, std::max(SD_STREAM_MAX_ROWS, geti("SD_GEMM_ROWS_MAX", SD_ROWS_MAX)));   // 65..this many rows take the balanced kernel, more the LDS-tiled one
     if (!g_env.cus) {
         int dev = 0, n = 0;
@@ -779,16 +780,21 @@ static int tp_reduce(sd_session *s, GemmOut *go, const float **src, int M, int N
     const int total = M * N;
     {
         ProfScope ps(s, PC_OTHER, st);
-        hipLaunchKernelGGL(tp_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, *src, go->S, go->stride_s, total, s->tp_in);
-        SD_LAUNCH_CHECK();
+        // one slab (the row-parallel GEMM kept its whole k-range per workgroup): its [M][N] rows ARE this rank's partial - no fold
+        const float *mine = *src;
+        if (go->S != 1) {
+            hipLaunchKernelGGL(tp_fold_kernel, dim3((total + 255) / 256), dim3(256), 0, st, *src, go->S, go->stride_s, total, s->tp_in);
+            SD_LAUNCH_CHECK();
+            mine = s->tp_in;
+        }
         if (t->comm) {
-            if (g_rccl.allreduce(s->tp_in, s->tp_out, (size_t)total, /* ncclFloat32 */ 7, /* ncclSum */ 0, t->comm, st) != 0) {
+            if (g_rccl.allreduce(mine, s->tp_out, (size_t)total, /* ncclFloat32 */ 7, /* ncclSum */ 0, t->comm, st) != 0) {
                 sd_set_error("ncclAllReduce failed");
                 return SD_ERR_HIP;
             }
         } else {
             TpLoop *L = t->loop;
-            L->bufs[t->rank] = s->tp_in;
+            L->bufs[t->rank] = mine;
             SD_HIP_CHECK(hipEventRecord(L->ev_in[t->rank], st));
             L->barrier();                                           // every rank's partial is enqueued
             TpBufs b = {};
@@ -856,8 +862,10 @@ static int dispatch_gemm_bf16(const void *W, const void *X, float *part, int M, 
 
 // X: [M][K] activations (M <= 64 per call; callers chunk), W: [N][K] weights -> split-K slabs in s->part
 template <typename H = bf16_t>
+// one_slab: the caller wants the whole k-range per workgroup where the shape allows it (a tensor-parallel shard's O / down
+// projection: its [M][N] partial then goes to the all-reduce as it is, without a fold launch in between)
 static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, int K, GemmOut *go, hipStream_t st,
-                    const RowTab *xtab = nullptr) {
+                    const RowTab *xtab = nullptr, bool one_slab = false) {
     const sd_model_config &c = s->m->cfg;
     ProfScope ps(s, PC_GEMM, st);
     if (is16(c.dtype)) {
@@ -865,7 +873,9 @@ static int run_gemm(sd_session *s, const void *W, const void *X, int M, int N, i
         if (xtab)
             for (int i = 0; i < M && xmap_identity; ++i) xmap_identity = xtab->xmap[i] == i;
         if (xmap_identity) xtab = nullptr;                        // every row in place (a verify pass): no gather
-        const GemmPlan pl = gemm_plan(N, K, M, xtab == nullptr);          // a row gather (lm_head) keeps the streaming kernel
+        GemmPlan pl = gemm_plan(N, K, M, xtab == nullptr);                // a row gather (lm_head) keeps the streaming kernel
+        // (<= 16 rows of a shard: one workgroup per n-tile over the whole k-range still gives >= 256 workgroups at hidden >= 4096)
+        if (one_slab && !pl.tiled && M <= 16 && N / 16 >= 256) { pl.S = 1; pl.ksp = K / 32; }
         const int S = pl.S, ksp = pl.ksp;
         const int Mpad = (int)align_up(M, 16);
         SD_REQUIRE((size_t)S * Mpad * N <= s->part_floats, "run_gemm: partial buffer too small");
@@ -1359,7 +1369,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
         }
         // output projection + residual (+ norm feeding the MLP)
-        if (!o_done && (rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st)) != SD_OK) return rc;
+        if (!o_done && (rc = run_gemm<H16>(s, m->wo[l], at, n_new, H, q_dim(c), &go, st, nullptr, s->tp && g_env.tp_one_slab)) != SD_OK) return rc;
         const float *osrc = s->part;
         if ((rc = tp_reduce(s, &go, &osrc, n_new, H, st)) != SD_OK) return rc;
         if (!xn_o) {
@@ -1403,7 +1413,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             if (xn_d && (rc = launch_gemm_fin<H16>(s, m->wdown[l], ac, n_new, H, I, nullptr, st)) != SD_OK) return rc;
         }
         if (xn_d) continue;
-        if ((rc = run_gemm<H16>(s, m->wdown[l], ac, n_new, H, I, &go, st)) != SD_OK) return rc;
+        if ((rc = run_gemm<H16>(s, m->wdown[l], ac, n_new, H, I, &go, st, nullptr, s->tp && g_env.tp_one_slab)) != SD_OK) return rc;
         const float *dsrc = s->part;
         if ((rc = tp_reduce(s, &go, &dsrc, n_new, H, st)) != SD_OK) return rc;
         {

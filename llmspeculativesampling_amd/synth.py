@@ -25,14 +25,15 @@ def param_shapes(cfg: ModelConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
     out: List[Tuple[str, Tuple[int, ...], str]] = []
     if cfg.arch == "llama":
         kv = cfg.num_key_value_heads * cfg.head_dim
+        qd = cfg.num_attention_heads * cfg.head_dim       # == h, except for a tensor-parallel shard's local geometry (tp.shard_config)
         out.append(("model.embed_tokens.weight", (cfg.vocab_size, h), "emb"))
         for i in range(L):
             p = f"model.layers.{i}."
             out += [
-                (p + "self_attn.q_proj.weight", (h, h), "mat"),
+                (p + "self_attn.q_proj.weight", (qd, h), "mat"),
                 (p + "self_attn.k_proj.weight", (kv, h), "mat"),
                 (p + "self_attn.v_proj.weight", (kv, h), "mat"),
-                (p + "self_attn.o_proj.weight", (h, h), "mat"),
+                (p + "self_attn.o_proj.weight", (h, qd), "mat"),
                 (p + "mlp.gate_proj.weight", (cfg.intermediate_size, h), "mat"),
                 (p + "mlp.up_proj.weight", (cfg.intermediate_size, h), "mat"),
                 (p + "mlp.down_proj.weight", (h, cfg.intermediate_size), "mat"),
