@@ -411,6 +411,11 @@ def main(argv=None):
     srank, sworld = (0, 1) if TP > 1 else (rank, world)      # tensor parallel: one stream per step for the whole group
     for i in range(args.warmup):
         run_step(srank + 10_000 * (i + 1))
+    if dist is not None and TP == 1:
+        # set-up, not work: the gather's communicator (ncclCommInitRank takes from a few hundred ms to seconds) and RCCL's
+        # first-collective warm-up belong in front of the timed region, whatever --warmup is
+        from llmspeculativesampling_amd.dist import gather_streams
+        gather_streams([torch.zeros((1, 4), dtype=torch.int64, device=comm_dev)], world, 8, device=comm_dev)
     barrier()
     t0 = time.time()
     new_tokens, acc_sum, n_iters = 0, 0, 0
