@@ -419,3 +419,33 @@ def test_tp8_loopback_llama70b_shard_shape_fp8_kv_vs_fp32_truth(hip):
         assert bool(((a - b).abs() <= 0.126 * torch.maximum(a.abs(), b.abs()) + 2e-3).all())      # one e4m3 step at most
 
 
+
+
+def test_fp16_many_row_passes_13b_layer_shape_vs_oracle(hip):
+    """The fp16 instances (v_mfma_f32_16x16x32_f16) of the balanced many-row GEMM at every m-tile count it is built for - a
+    132-row prefill chunk (9 m-tiles), then 72-, 40-, 24- and 100-row chunks (5, 3, 2 and 8 m-tiles) of ONE sequence at
+    Llama-2-13b's layer shape, 2 layers - against the oracle's fp16 forward (what evaluation.py:185 loads): the last five
+    logit rows of every chunk within 0.5 % of the logit scale (fp16's bar in tests/test_gpu_native_parity.py), and the fp16
+    K / V rows of the last layer likewise."""
+    cfg = _llama13b_layers(2)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=13, dtype=torch.float16, max_pos=384, gain=0.5)
+    sd = _host_sd(m)
+    om = oracle.RefCausalLM(cfg, sd)
+    ses = m.new_session(384)
+    ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 368)))
+    past, pos = None, 0
+    for q in (132, 72, 40, 24, 100):
+        chunk = ids[:, pos:pos + q]
+        o = om(chunk, past_key_values=past)
+        past = o.past_key_values
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), 5).cpu()
+        want = o.logits.float()[0, -5:]
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        print(f"fp16, {q}-row chunk at position {pos}: |logit| max {scale:.2f}, max err {err:.4f}")
+        assert err <= 0.005 * scale + 2e-3, (q, err, scale)
+        pos += q
+    k, v = ses.past_key_values()[1]
+    ok, ov = past[1]
+    assert float((k.float().cpu() - ok.float()).abs().max()) <= 0.01 * max(1.0, float(ok.float().abs().max()))
+    assert float((v.float().cpu() - ov.float()).abs().max()) <= 0.01 * max(1.0, float(ov.float().abs().max()))
