@@ -151,7 +151,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
+    int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
 static void refresh_env() {
@@ -170,6 +170,7 @@ static void refresh_env() {
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
+    g_env.wide_qkv = geti("SD_WIDE_QKV", 1);          // 0: a QKV projection with <= 128 n-tiles keeps one 4-wave workgroup per tile (A/B, compare tests)
     g_env.tp_one_slab = geti("SD_TP_ONE_SLAB", 1);    // 0: a shard's O / down projection keeps its k-slabs + the fold launch in front of the all-reduce (A/B)
     g_env.rows_max = std::min(SD_ROWS_MAX, std::max(SD_STREAM_MAX_ROWS, geti("SD_GEMM_ROWS_MAX", SD_ROWS_MAX)));   // 65..this many rows take the balanced kernel, more the LDS-tiled one
     if (!g_env.cus) {
@@ -916,6 +917,15 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
                           hipStream_t st) {
     ProfScope ps(s, PC_GEMM, st);
     const int Mpad = (int)align_up(M, 16);
+    // few n-tiles and a long k-range (a tensor-parallel shard's QKV: 80 tiles x K = 8192): sixteen waves per tile
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_QKV_PLAIN) {
+        if (g_env.wide_qkv && M <= 16 && !e.use_xmap && !e.x_rowmajor && N / 16 <= 128 && K / 32 >= 128) {
+            hipLaunchKernelGGL((gemm_bf16_stream_w16<EPI, H, 16>), dim3(N / 16), dim3(1024), 0, st, (const u32x4 *)W, (const H *)X, M, N, K, e);
+            SD_LAUNCH_CHECK();
+            return SD_OK;
+        }
+    }
+    // (eight waves per tile for a shard's gate/up - 448 n-tiles - measured slower: 5.94 against 5.86 ms per verify)
     const RowsPlan rp = (e.use_xmap || e.x_rowmajor) ? RowsPlan{} : rows_plan(N, K, M, true);
     const int rc = rp.ok ? launch_gemm_rows<EPI, H>(W, X, nullptr, M, Mpad, N, K, rp, e, st)
                          : dispatch_gemm_bf16<EPI, H>(W, X, nullptr, M, Mpad, N, K, 1, K / 32, e, st);

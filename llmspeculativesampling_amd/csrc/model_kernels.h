@@ -464,6 +464,66 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// The same GEMM for a matrix with FEW n-tiles and a long k-range (<= 16 rows, SB = 1, fused epilogue) - the QKV projection
+// of a tensor-parallel shard: (8 + 2) heads x 128 = 80 n-tiles x K = 8192 (BASELINE config 5).  One 4-wave workgroup per
+// tile puts 80 workgroups with 16 KiB in flight each on 256 CUs: 15 us for 21 MB.  Here a workgroup is SIXTEEN waves on one
+// tile, each wave a sixteenth of the k-range (groups of four k-steps, bursts like gemm_bf16_stream), so that a CU has 64 KiB
+// in flight and draws several times its fair share of an HBM that is otherwise idle; the sixteen partial sums fold
+// through LDS in a fixed order ((((w0 + w1) + (w2 + w3)) + ...) pairwise) and the tile's epilogue runs once.
+// ------------------------------------------------------------------------------------------
+template <int EPI, typename H = bf16_t, int NW = 16>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_stream_w16(const u32x4 *__restrict__ Wp, const H *__restrict__ X, int M, int N,
+                                                              int K, GemmEpiT<H> e) {
+    constexpr int U = 4;                                          // (NW = 16, or 8 for matrices with a few hundred n-tiles)
+    __shared__ f32x4 red[NW][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int KS = K >> 5, ntg = blockIdx.x;
+    const int per = (KS + NW - 1) / NW;
+    const int ks0 = min(KS, wv * per), ks1 = min(KS, ks0 + per), ksa = min(ks0, KS - 1);
+    const u32x4 *wp = Wp + ((size_t)ntg * KS + ksa) * 64 + lane;
+    const int mrow = (lane & 15) < M ? (lane & 15) : 0;           // rows >= M read row 0 (their output columns are dropped)
+    const H *xp = X + (size_t)ksa * 512 + ((lane >> 4) * 16 + mrow) * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int ks = ks0;
+    for (; ks + U <= ks1; ks += U) {
+        u32x4 w[U], x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (size_t)u * 64);
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const u32x4 *>(xp + u * 512);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16<H>(w[u], x[u], acc);
+        wp += (size_t)U * 64; xp += U * 512;
+    }
+    if (ks < ks1) {                                               // the last < 4 k-steps as one burst (clamped, zeroed at use)
+        const int rem = ks1 - ks;
+        u32x4 w[U - 1], x[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) {
+            w[u] = __builtin_nontemporal_load(wp + (size_t)min(u, rem - 1) * 64);
+            x[u] = *reinterpret_cast<const u32x4 *>(xp + min(u, rem - 1) * 512);
+        }
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) {
+            u32x4 wz = w[u];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wz[q] = u < rem ? wz[q] : 0u;
+            acc = mfma16<H>(wz, x[u], acc);
+        }
+    }
+    red[wv][lane] = acc;
+    __syncthreads();
+    auto folded = [&](int, int l) -> f32x4 {
+        f32x4 q[NW / 4];
+#pragma unroll
+        for (int g = 0; g < NW / 4; ++g) q[g] = (red[4 * g][l] + red[4 * g + 1][l]) + (red[4 * g + 2][l] + red[4 * g + 3][l]);
+        if constexpr (NW == 16) return (q[0] + q[1]) + (q[2] + q[3]);
+        else return q[0] + q[1];
+    };
+    if (threadIdx.x < 64) gemm_epilogue_fold<1, EPI, 1, 1, H>(folded, 0, (float *)nullptr, M, 16, N, 0, ntg, e, (int)threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
 // Many-row GEMM (prefill, wide stream batches): part[sb][m][n] = sum_{k in slab sb} X[m][k] * W[n][k]
 // One workgroup = 2 x 2 waves on a (2*NTWV n-tiles) x (2*MTW m-tiles) block of the output; per k-step (32 columns of
 // K) its W and X tiles - both already stored in MFMA fragment order, 1 KiB each - are copied once into LDS (double
