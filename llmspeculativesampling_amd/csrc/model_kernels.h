@@ -95,8 +95,7 @@ enum { RES_PRE = 0, RES_POST = 1, RES_NONE = 2 };   // norm after the residual f
 // The MFMA runs with A = W tile (rows n), B = X^T (cols m): lane holds D[n = 4*(lane>>4)+j][m = lane&15],
 // so each lane stores 4 consecutive n as one float4.
 // ------------------------------------------------------------------------------------------
-enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4, EPI_HEAD = 5,
-       EPI_RESID = 6 };      // (rows_kernels.h only: k-split slabs + ticket, the last workgroup of an n-group adds the residual)
+enum { EPI_PART = 0, EPI_ACT_SILU = 1, EPI_ACT_RELU = 2, EPI_QKV_ROPE = 3, EPI_QKV_PLAIN = 4, EPI_HEAD = 5 };
 
 // Arguments of the fused epilogues (SB == 1: the workgroup holds the whole dot product after its LDS fold).
 // ---- fp8 (OCP e4m3, gfx950's native form) KV arena: x is stored as fp8(x / scale), read back as fp8 * scale.  The
@@ -152,9 +151,6 @@ struct GemmEpiT {
     // tile layout, and the per-tile sums of squares [M][N/16] for the consumer's norm on load
     H *res_x, *res_h;
     float *res_ssq;
-    // EPI_RESID (rows_kernels.h): one arrival counter per n-group (monotonic) and its value before this launch
-    unsigned *tk_ctr;
-    unsigned tk_base;
     RowTab tab;
 };
 using GemmEpi = GemmEpiT<bf16_t>;
@@ -189,26 +185,6 @@ __device__ __forceinline__ void store4_maybe_wt(H *dst, float a, float b, float 
     else *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(v);
 }
 
-// rnd(w * rnd(x * r)) on 8 packed elements: one fragment of an RMSNorm applied on the way into an MFMA (norm on load:
-// normload_kernels.h for <= 8 rows, rows_kernels.h for 17-80)
-template <typename H>
-__device__ __forceinline__ u32x4 norm_frag(u32x4 x, u32x4 g, float r) {
-#pragma clang fp contract(off)
-    H xv[8], gv[8], o[8];
-    *reinterpret_cast<u32x4 *>(xv) = x;
-    *reinterpret_cast<u32x4 *>(gv) = g;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (H)(to_f(gv[i]) * to_f((H)(to_f(xv[i]) * r)));
-    return *reinterpret_cast<const u32x4 *>(o);
-}
-// 16 bytes another workgroup of this launch stored write-through: two 8-byte sc1 loads (relaxed agent-scope atomics lower
-// to global_load_dwordx2 sc1 - L1 bypassed, served by L2 / memory)
-__device__ __forceinline__ f32x4 load_f32x4_sc1(const float *p) {
-    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
-                 __uint_as_float((unsigned)(b >> 32))};
-}
 // One fold step of the streaming GEMMs' epilogue: red[wave][pp][lane] holds the 4 waves' accumulators of PT tiles; the
 // folded sums go to the split-K slab (EPI_PART / EPI_HEAD) or through the fused epilogue.  Shared by gemm_bf16_stream and
 // gemm_small (small_kernels.h).

@@ -27,6 +27,16 @@
 // The prologue (partials, norm weight to LDS by DMA, one barrier) runs behind the first group's weight requests, which
 // are issued first-needed last (VMEM returns in order): norm weight, partials, then the weights.
 #define XN_MAX4 5                                             // 16-byte pieces of partials per lane per pass (hidden <= 5120: one pass)
+template <typename H>
+__device__ __forceinline__ u32x4 norm_frag(u32x4 x, u32x4 g, float r) {
+#pragma clang fp contract(off)
+    H xv[8], gv[8], o[8];
+    *reinterpret_cast<u32x4 *>(xv) = x;
+    *reinterpret_cast<u32x4 *>(gv) = g;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (H)(to_f(gv[i]) * to_f((H)(to_f(xv[i]) * r)));
+    return *reinterpret_cast<const u32x4 *>(o);
+}
 // C: k-steps whose M valid rows fit one conversion register (C * 4 * M <= 64 lanes).  Weight requests stay in groups of
 // four k-steps (the streaming kernel's measured optimum; groups of three ran 4 % slower whatever the conversion cost), so
 // a group takes NCV = ceil(4 / C) conversions, the last one covering what is left of the four.
@@ -159,6 +169,14 @@ __global__ __launch_bounds__(256, 8) void gemm_bf16_stream_xn(const u32x4 *__res
 // monotonic (the host passes the arrivals expected so far; compared as a signed difference); a wait that exceeds 20 ms
 // poisons the tile with NaN, which the sampler reports - a timed-out launch never returns plausible numbers.
 #define FIN_TIMEOUT_TICKS 2000000ll                           // wall_clock64 runs at 100 MHz
+// 16 bytes another workgroup of this launch stored write-through: two 8-byte sc1 loads (relaxed agent-scope atomics lower
+// to global_load_dwordx2 sc1 - L1 bypassed, served by L2 / memory)
+__device__ __forceinline__ f32x4 load_f32x4_sc1(const float *p) {
+    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                 __uint_as_float((unsigned)(b >> 32))};
+}
 template <typename H = bf16_t>
 __global__ __launch_bounds__(256) void gemm_bf16_stream_fin(const u32x4 *__restrict__ Wp, const H *__restrict__ X,
                                                            float *__restrict__ part, int M, int N, int K, int SB,

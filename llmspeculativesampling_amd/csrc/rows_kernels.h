@@ -42,24 +42,7 @@ __device__ __forceinline__ void gr_glds16(const u32x4 *gsrc, unsigned lds_dst) {
 // double-buffered panel only fits the CU's LDS with CH = 4, and bursts of 4 KiB per wave leave too few bytes in flight
 // (8-12 compute waves x 4 KiB against the ~50 KiB a CU needs outstanding to draw its share of HBM): the burst then spans
 // two chunks (8 KiB) and is requested on every second one.
-//
-// XN (stream-batched verify, Llama): the activation rows arrive UN-normalised (left by an EPI_RESID producer together
-// with one sum of squares per row and 16-column tile) and the RMSNorm is applied while the panel is staged: the loader
-// waves read the fragments into registers, scale them - rnd(w * rnd(x * r)), element for element what
-// residual_norm_kernel stores - and write them to the panel (ds_write_b128) instead of LDS-DMA; the row factors r come
-// from a prologue in which all threads add up the row's partials in a fixed order (16 threads per row, 20 consecutive
-// partials each at hidden 5120, then a 16-lane DPP sum).  The compute waves request their first weight burst before that
-// prologue.  With EPI_RESID on the producing side this removes the two residual+norm launches of a layer.
-//
-// EPI_RESID (the producer: O / down projection, k-split over S workgroups per n-group): every workgroup stores its
-// partial sums write-through into TILE-MAJOR slabs [S][N/16][Mpad][16], drains its stores and takes a ticket on its
-// n-group's counter (one agent-scope add that returns the old value); the workgroup whose ticket is the last adds the S
-// slabs in slab order (((s0 + s1) + s2) + s3: reduce_part4's order, so x' equals the launch path's bit for bit), forms
-// x' = rnd(x + rnd(sum + bias)), stores it to the residual rows and - un-normalised - to the operand layout, and leaves the
-// tile's sum of squares per row.  Nobody waits for anybody: no spin, no timeout, no residency assumption
-// (MI355X_MICROARCH.md, "inter-workgroup visibility": sc1 stores, every storing wave drained, a workgroup barrier, ONE
-// lane's returning add; the last adder loads with sc1 after its add returned, its other waves after a barrier).
-template <int MT, int EPI, typename H = bf16_t, int CH = 8, int WBM = 1, bool XN = false>
+template <int MT, int EPI, typename H = bf16_t, int CH = 8, int WBM = 1>
 // (WBM is 1 or 2)
 __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__restrict__ Wp, const u32x4 *__restrict__ Xp,
                                                             float *__restrict__ part, int M, int Mpad, int N, int K,
@@ -91,44 +74,6 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ni = wv % nwn, kg = wv / nwn;                       // (meaningful for compute waves)
     const bool comp = wv < ncomp && t0 + ni < t1;
-    // compute waves: k-range and weight stream (the first burst may go out before the XN prologue)
-    const int cks0 = min(kb1, kb0 + kg * per), cks1 = min(kb1, cks0 + per), nk = comp ? cks1 - cks0 : 0;
-    const u32x4 *wp = Wp + ((size_t)(t0 + min(ni, max(t1 - t0 - 1, 0))) * KS + min(cks0, KS - 1)) * 64 + lane;
-    u32x4 w[WB];
-    auto burst = [&](int k0) {
-        if (k0 + WB <= nk) {                                      // a whole burst: WB back-to-back requests, no branch between
-#pragma unroll
-            for (int u = 0; u < WB; ++u)
-                w[u] = (probe & 8) ? u32x4{0u, 0u, 0u, 0u} : __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
-        } else {
-#pragma unroll
-            for (int u = 0; u < WB; ++u) {
-                w[u] = u32x4{0u, 0u, 0u, 0u};
-                if (k0 + u < nk && !(probe & 8)) w[u] = __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
-            }
-        }
-    };
-    __shared__ float xn_r[XN ? MT * 16 : 1];                      // XN: the rows' RMSNorm factors
-    if constexpr (XN) {
-        if (comp) burst(0);
-        // row totals: thread (row = tid / 16, piece = tid % 16) adds nt / 16 consecutive partials in sequence, the 16 pieces
-        // of a row fold with the first four DPP steps of wave_sum (xor 1, xor 2, half mirror, mirror: a 16-lane row)
-        const int nt = e.nrm_nt, pern = nt >> 4;
-        for (int r0 = 0; r0 < MT * 16; r0 += GR_THREADS / 16) {
-            const int row = r0 + (int)(threadIdx.x >> 4), piece = (int)(threadIdx.x & 15);
-            float a = 0.f;
-            if (row < M) {
-                const float *sp = e.nrm_ssq + (size_t)row * nt + piece * pern;
-                for (int j = 0; j < pern; ++j) a += sp[j];
-            }
-            a += dpp_mov<0xB1, 0xF>(a, 0.f);
-            a += dpp_mov<0x4E, 0xF>(a, 0.f);
-            a += dpp_mov<0x141, 0xF>(a, 0.f);
-            a += dpp_mov<0x140, 0xF>(a, 0.f);
-            if (piece == 0 && row < MT * 16) xn_r[row] = row < M ? rsqrtf(a / (float)K + e.nrm_eps) : 0.f;
-        }
-        __syncthreads();
-    }
 
     if (wv >= ncomp && wv < ncomp + nld) {
         // ---------------- loader: k-groups ld, ld + nld, ... ----------------
@@ -138,29 +83,6 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
             for (int k2 = ld; k2 < nwk; k2 += nld) {
                 const int ks0 = min(kb1, kb0 + k2 * per), ks1 = min(kb1, ks0 + per);
                 if (ks0 >= ks1) continue;                         // (an empty k-group: its compute waves multiply nothing)
-                if constexpr (XN) {
-                    // registers instead of LDS-DMA: two k-steps' fragments (+ their norm weights) per round trip
-                    const H *nw = e.nrm_w + (lane >> 4) * 8;
-                    float rr[MT];
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) rr[t] = xn_r[min(t, mt_valid - 1) * 16 + (lane & 15)];
-#pragma unroll
-                    for (int c2 = 0; c2 < CH; c2 += 2) {
-                        u32x4 xv[2][MT], gv[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int ks = min(ks0 + c * CH + c2 + u, ks1 - 1);
-                            gv[u] = *reinterpret_cast<const u32x4 *>(nw + (size_t)ks * 32);
-#pragma unroll
-                            for (int t = 0; t < MT; ++t) xv[u][t] = Xp[((size_t)min(t, mt_valid - 1) * KS + ks) * 64 + lane];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-#pragma unroll
-                            for (int t = 0; t < MT; ++t) xs[buf * nwk + k2][c2 + u][t][lane] = norm_frag<H>(xv[u][t], gv[u], rr[t]);
-                    }
-                    continue;
-                }
                 const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(
                     (int)(unsigned)(uintptr_t)&xs[buf * nwk + k2][0][0][0]);               // LDS byte address (wave-uniform)
 #pragma unroll
@@ -185,6 +107,9 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
         }
     } else if (comp) {
         // ---------------- compute: tile t0 + ni, k-group kg ----------------
+        const int ks0 = min(kb1, kb0 + kg * per), ks1 = min(kb1, ks0 + per);
+        const int nk = ks1 - ks0;
+        const u32x4 *wp = Wp + ((size_t)(t0 + ni) * KS + min(ks0, KS - 1)) * 64 + lane;
         // BURSTS, not a ring: a burst's WB weight tiles (WB KiB, contiguous) are requested together and multiplied when
         // they have all landed; the other compute waves of the CU cover the wait.  Measured against a 4-slot register
         // ring that kept three chunks in flight (tools/gemm_bench.py rows, 40 rows): gate/up 51.5 -> 48.3 us, O 16.2 ->
@@ -192,9 +117,23 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
         // request-all-then-multiply groups beat every prefetching variant tried.
         // A k-step past the wave's range is not requested and multiplied as ZERO against the panel tile it meets (which
         // holds finite values: the loader clamps); every operand register is written on every path.
+        u32x4 w[WB];
         for (int c = 0; c < nch; ++c) {
             bar();                                                // chunk c's panel is in LDS
-            if (c % WBM == 0 && !(XN && c == 0)) burst(c * CH);   // (XN: burst 0 went out before the prologue)
+            if (c % WBM == 0) {
+                const int k0 = c * CH;
+                if (k0 + WB <= nk) {                              // a whole burst: WB back-to-back requests, no branch between
+#pragma unroll
+                    for (int u = 0; u < WB; ++u)
+                        w[u] = (probe & 8) ? u32x4{0u, 0u, 0u, 0u} : __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < WB; ++u) {
+                        w[u] = u32x4{0u, 0u, 0u, 0u};
+                        if (k0 + u < nk && !(probe & 8)) w[u] = __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
+                    }
+                }
+            }
             const int pbuf = (c & 1) * nwk + kg;
             const int wb0 = (c % WBM) * CH;
 #pragma unroll
@@ -229,59 +168,16 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
     }
     __syncthreads();
     constexpr int EL = (EPI == EPI_ACT_SILU ? 32 : 64) * MT;      // threads one tile's epilogue takes (SiLU pairs gate / up lanes)
-    auto kfold = [&](int g4, int pp, int l) -> f32x4 {
+    for (int i = (int)threadIdx.x; i < nwn * EL; i += GR_THREADS) {
+        const int g4 = i / EL, tile = t0 + g4;
+        if (tile >= t1) continue;
         f32x4 (*rt)[MT][64] = red + (size_t)g4 * nwk;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = rt[0][pp][l], s1 = nwk > 1 ? rt[1][pp][l] : z, s2 = nwk > 2 ? rt[2][pp][l] : z,
-                    s3 = nwk > 3 ? rt[3][pp][l] : z;
-        return (s0 + s1) + (s2 + s3);
-    };
-    if constexpr (EPI == EPI_RESID) {
-#pragma clang fp contract(off)
-        const int SB = (int)gridDim.x / NG;
-        auto slab = [&](int s2, int tile, int m) { return part + (((size_t)s2 * NT + tile) * Mpad + m) * 16; };
-        for (int i = (int)threadIdx.x; i < nwn * EL; i += GR_THREADS) {           // 1. this workgroup's partial sums, write-through
-            const int g4 = i / EL, tile = t0 + g4, r = i - g4 * EL, pp = r >> 6, l = r & 63, m = pp * 16 + (l & 15);
-            if (tile < t1 && m < M) store_f32x4<true>(slab(sb, tile, m) + (l >> 4) * 4, kfold(g4, pp, l));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // every storing wave has drained
-        __shared__ int last_sh;
-        __syncthreads();
-        if (threadIdx.x == 0) {                                                   // 2. the ticket
-            const unsigned old = __hip_atomic_fetch_add(e.tk_ctr + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_sh = (old - e.tk_base) == (unsigned)(SB - 1);
-        }
-        __syncthreads();
-        if (!last_sh) return;
-        for (int i = (int)threadIdx.x; i < nwn * EL; i += GR_THREADS) {           // 3. the last workgroup of the n-group finishes
-            const int g4 = i / EL, tile = t0 + g4, r = i - g4 * EL, pp = r >> 6, l = r & 63, m = pp * 16 + (l & 15);
-            const int col = tile * 16 + (l >> 4) * 4;
-            float a2 = 0.f;
-            if (tile < t1 && m < M) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int s2 = 0; s2 < SB; ++s2) a += load_f32x4_sc1(slab(s2, tile, m) + (l >> 4) * 4);
-                H xin[4], v[4];
-                *reinterpret_cast<uint2 *>(xin) = *reinterpret_cast<const uint2 *>(e.res_x + (size_t)m * N + col);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float y = a[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f);
-                    const float f = rnd<H>(to_f(xin[c]) + rnd<H>(y));
-                    v[c] = (H)f;
-                    a2 += f * f;
-                }
-                *reinterpret_cast<uint2 *>(e.res_x + (size_t)m * N + col) = *reinterpret_cast<const uint2 *>(v);
-                *reinterpret_cast<uint2 *>(e.res_h + xoff<H>(m, col, N)) = *reinterpret_cast<const uint2 *>(v);
-            }
-            a2 += __shfl_xor(a2, 16, 64);                                         // (the four quads of a row: (q0 + q1) + (q2 + q3))
-            a2 += __shfl_xor(a2, 32, 64);
-            if (tile < t1 && m < M && l < 16) e.res_ssq[(size_t)m * NT + tile] = a2;
-        }
-    } else {
-        for (int i = (int)threadIdx.x; i < nwn * EL; i += GR_THREADS) {
-            const int g4 = i / EL, tile = t0 + g4;
-            if (tile >= t1) continue;
-            auto folded = [&](int pp, int l) -> f32x4 { return kfold(g4, pp, l); };
-            gemm_epilogue_fold<MT, EPI, 1, MT, H>(folded, 0, part, M, Mpad, N, sb, tile, e, i - g4 * EL);
-        }
+        auto folded = [&](int pp, int l) -> f32x4 {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 s0 = rt[0][pp][l], s1 = nwk > 1 ? rt[1][pp][l] : z, s2 = nwk > 2 ? rt[2][pp][l] : z,
+                        s3 = nwk > 3 ? rt[3][pp][l] : z;
+            return (s0 + s1) + (s2 + s3);
+        };
+        gemm_epilogue_fold<MT, EPI, 1, MT, H>(folded, 0, part, M, Mpad, N, sb, tile, e, i - g4 * EL);
     }
 }
