@@ -71,6 +71,10 @@ struct sd_session {
     // clears the probability rows head_zero_rows + i * head_zero_ld of its logit rows (see EPI_HEAD)
     float *head_zero_rows;
     long head_zero_ld;
+    // (stream-batched pass: the logit rows' probability rows lie in the streams' own arenas - one pointer per logit row,
+    //  head_zero_n of them, instead of head_zero_rows + i * head_zero_ld)
+    float *head_zero_ptr[16];
+    int head_zero_n;
     const float *last_tile_max;
     // profiling
     int prof_on;
@@ -483,6 +487,7 @@ extern "C" int sd_session_create(sd_model *m, int max_seq, int max_rows, void *k
     s->tp_out = (float *)(s->scratch + p.tp_out);
     s->head_zero_rows = nullptr;
     s->head_zero_ld = 0;
+    s->head_zero_n = 0;
     s->last_tile_max = nullptr;
     s->h = s->scratch + p.h;
     s->h2 = s->scratch + p.h2;
@@ -1459,11 +1464,14 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
         const int round_t = (c.logits_bf16_round || !llama) ? round_code(c.dtype) : 0;
         // native iteration: the head also leaves the maximum of every 16-column tile and clears the probability rows, so
         // the normalisation that follows needs no candidate pass over V (EPI_HEAD; whole k-range per workgroup)
-        if (is16(c.dtype) && s->want_raw_logits && s->head_zero_rows && n_logits <= 16 && c.vocab % 16 == 0 &&
+        const bool zero_tab = !s->head_zero_rows && s->head_zero_n > 0 && s->head_zero_n == n_logits;
+        if (is16(c.dtype) && s->want_raw_logits && (s->head_zero_rows || zero_tab) && n_logits <= 16 && c.vocab % 16 == 0 &&
             gemm_plan(c.vocab, ED, n_logits, false).S == 1 && !gemm_plan(c.vocab, ED, n_logits, false).tiled) {
             GemmEpiT<H16> e = {};
             if (xt) { e.use_xmap = 1; e.tab = *xt; }
             e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
+            if (zero_tab)
+                for (int i = 0; i < n_logits; ++i) e.zero_ptr[i] = s->head_zero_ptr[i];
             {
                 ProfScope ps(s, PC_GEMM, st);
                 launch_gemm_bf16<1, EPI_HEAD, 1, H16>(m->w.lm_head, hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
@@ -1939,6 +1947,11 @@ int sd_norm_rows_with_tiles(const float *logits, int rows, int V, long ld_in, fl
                             uint64_t draw, int *tok_out, int *samp_err, void *workspace, const float *tile_max,
                             void *stream, void *cand_lists);
 size_t sd_norm_candrow_bytes(int rows);
+int sd_norm_batch_tiles(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                        int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace, const float *tile_max,
+                        void *cand_lists, void *stream);
+int sd_accept_resample_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, int dtype_mode,
+                             const void *const *lists, void *stream);
 
 // feed seq[from, upto) in chunks of at most max_rows; logits come out for the last n_logits rows, all of them from the
 // final call (a chunk never ends inside the logits rows), so that call's output slab can be handed to the norm as is
@@ -2151,7 +2164,9 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
                    "sd_spec_batch_generate: the streams' result blocks must be consecutive");
     hipStream_t st = (hipStream_t)stream;
     const int g = gamma, n_err = 3 * g + 1;
-    const int max_verify = std::max(1, max_rows_per_forward / (g + 1));        // streams per target pass
+    // streams per target pass (a 16-bit model whose GEMMs cannot take the tiled kernel carries 64 rows per forward, not 80)
+    const int pass_rows = std::min({max_rows_per_forward, streams[0].target ? streams[0].target->max_rows : max_rows_per_forward, SD_MAX_ROWS});
+    const int max_verify = std::max(1, pass_rows / (g + 1));
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess ||
         hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess) {
@@ -2168,6 +2183,13 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
     std::vector<sd_batch_item> items;
     std::vector<sd_norm_row> rows;
     std::vector<sd_accept_item> aitems;
+    std::vector<const void *> list_of;
+    // SD_BATCH_FUSED_TAIL=0: the round-1 sampling tail (logits copy, candidate pass + norm per draft step; dense accept scan +
+    // resample) - kept for A/B runs and as the reference the fused tail is tested against; read per call
+    const bool fused_tail = !(getenv("SD_BATCH_FUSED_TAIL") && atoi(getenv("SD_BATCH_FUSED_TAIL")) == 0);
+    // EPI_HEAD's tile maxima serve the top-k candidate search only (as in sd_spec_iteration)
+    const bool tiles_ok = top_k >= 1 && top_k <= 64 && temperature > 0.0f && V % 16 == 0 && V >= 4096 && V <= 65536 &&
+                          ld % 4 == 0 && g_env.head_tiles;
     for (int i = 0; i < n_streams; ++i) { streams[i].done = 0; streams[i].calls = 0; }
     for (;;) {
         act.clear();
@@ -2187,6 +2209,12 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
             act[j]->draw += (uint64_t)g;
             ctx += Ls[j];
         }
+        // the residual / bonus sample works on the target rows' candidate lists when ONE verify pass holds all streams (the
+        // workspace keeps the lists of one pass)
+        const bool lists_on = fused_tail && norm_workspace && n <= max_verify;
+        char *const list_base = norm_workspace ? (char *)norm_workspace + sd_norm_candrow_bytes(max_rows_per_forward) : nullptr;
+        const size_t list_stride = sd_cand_list_bytes(1);
+        list_of.assign(n, nullptr);
         // ---- draft: gamma steps over all active streams
         for (int i = 0; i < g && rc == SD_OK; ++i) {
             items.assign(n, sd_batch_item{});
@@ -2204,9 +2232,25 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
                 rows[j].sample_err = s.err_words + g + i;
                 s.draft_len = Ls[j] + i;
             }
-            if ((rc = sd_batch_forward(items.data(), n, draft_logits, ld_draft_logits, stream)) != SD_OK) break;
-            rc = sd_norm_batch(draft_logits, n, V, ld_draft_logits, temperature, top_k, top_p, draft_norm_mode, rows.data(), 1,
-                               norm_workspace, stream);
+            // the single-stream loop's sampler feed (sd_spec_iteration): the head leaves the logits in its own slab, the
+            // maximum of every 16-column tile, and clears the streams' probability rows - no logits copy, no candidate pass
+            sd_session *d0 = act[0]->draft;
+            if (fused_tail) {
+                d0->want_raw_logits = 1;
+                d0->head_zero_n = tiles_ok && n <= 16 ? n : 0;
+                for (int j = 0; j < d0->head_zero_n; ++j) d0->head_zero_ptr[j] = rows[j].probs_out;
+            }
+            rc = sd_batch_forward(items.data(), n, draft_logits, ld_draft_logits, stream);
+            d0->want_raw_logits = 0;
+            d0->head_zero_n = 0;
+            if (rc != SD_OK) break;
+            if (fused_tail)
+                rc = sd_norm_batch_tiles(d0->last_logits, n, V, d0->last_logits_ld, temperature, top_k, top_p,
+                                         d0->last_logits_round | draft_norm_mode, rows.data(), 1, norm_workspace, d0->last_tile_max,
+                                         nullptr, stream);
+            else
+                rc = sd_norm_batch(draft_logits, n, V, ld_draft_logits, temperature, top_k, top_p, draft_norm_mode, rows.data(), 1,
+                                   norm_workspace, stream);
         }
         if (rc != SD_OK) break;
         // ---- verify: the uncached rows of every stream, max_verify streams per pass over the target weights
@@ -2228,8 +2272,17 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
                 }
             }
             if ((rc = sd_batch_forward(items.data(), m, target_logits, ld_target_logits, stream)) != SD_OK) break;
-            rc = sd_norm_batch(target_logits, (int)rows.size(), V, ld_target_logits, temperature, top_k, top_p, target_norm_mode,
-                               rows.data(), 0, norm_workspace, stream);
+            // one pass holds every stream: the rows' candidate lists (behind the CandRows of the workspace) serve the
+            // residual / bonus sample below
+            rc = sd_norm_batch_tiles(target_logits, (int)rows.size(), V, ld_target_logits, temperature, top_k, top_p, target_norm_mode,
+                                     rows.data(), 0, norm_workspace, nullptr, lists_on ? list_base : nullptr, stream);
+            if (lists_on) {
+                int r0 = 0;
+                for (int j = 0; j < m; ++j) {                       // stream j's lists are valid when all its gamma + 1 rows are here
+                    list_of[a0 + j] = items[j].n_new == g + 1 ? list_base + (size_t)r0 * list_stride : nullptr;
+                    r0 += items[j].n_new;
+                }
+            }
         }
         if (rc != SD_OK) break;
         SD_LOOP_HIP(hipEventRecord(ev1, st));
@@ -2248,7 +2301,9 @@ extern "C" int sd_spec_batch_generate(sd_batch_stream *streams, int n_streams, i
             it.res = s.res_dev; it.err_flags = s.err_words; it.n_err = n_err;
         }
         const int res_mode = target_norm_mode == draft_norm_mode ? target_norm_mode : 0;
-        if ((rc = sd_accept_batch(aitems.data(), n, ld, V, g, res_mode, stream)) != SD_OK) break;
+        if (lists_on) rc = sd_accept_resample_batch(aitems.data(), n, ld, V, g, res_mode, list_of.data(), stream);
+        else rc = sd_accept_batch(aitems.data(), n, ld, V, g, res_mode, stream);
+        if (rc != SD_OK) break;
         SD_LOOP_HIP(hipMemcpyAsync(streams[0].res_host, streams[0].res_dev, sizeof(sd_accept_result) * (size_t)n_streams,
                                    hipMemcpyDeviceToHost, st));
         SD_LOOP_HIP(hipEventRecord(ev_done, st));

@@ -141,6 +141,7 @@ struct GemmEpiT {
     float *tile_max;
     float *zero_rows;
     long zero_ld;
+    float *zero_ptr[16];      // zero_rows == NULL: row m's probability row (the rows of a stream-batched pass lie in different arenas)
     // norm on load (gemm_bf16_stream_xn): X holds the UN-normalised residual rows; nrm_ssq[m][nrm_nt] the per-16-column
     // sums of their squares (left by the producing epilogue), nrm_w the RMSNorm weight [K]
     const float *nrm_ssq;
@@ -214,8 +215,8 @@ __device__ __forceinline__ void gemm_epilogue_fold(FoldFn folded, int fs, float 
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)); bad |= __shfl_xor(bad, 32, 64);
             if (m < M) {
                 *reinterpret_cast<f32x4 *>(part + (size_t)m * N + nt * 16 + (l >> 4) * 4) = r;
-                if (e.zero_rows)
-                    *reinterpret_cast<f32x4 *>(e.zero_rows + (size_t)m * e.zero_ld + nt * 16 + (l >> 4) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                float *zr = e.zero_rows ? e.zero_rows + (size_t)m * e.zero_ld : e.zero_ptr[m];
+                if (zr) *reinterpret_cast<f32x4 *>(zr + nt * 16 + (l >> 4) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (l < 16) e.tile_max[(size_t)m * (N >> 4) + nt] = bad ? __uint_as_float(0x7fc00000u) : mx;
             }
         }
@@ -406,26 +407,60 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
         // the last < UNROLL k-steps as ONE burst as well (requested together, multiplied in order): taken one at a time they
         // cost a memory round trip each - three of a wave's seven at the draft model's K = 768, three on top of six groups
         // in the 13b down projection
+        // EPI_PART with UNROLL = 8 takes a form with no branch around a load or an MFMA: with `if (u < rem)` around each of
+        // the seven steps hipcc built a divergent-branch ladder with ~900 register moves for that one instance -
+        // gemm_bf16_stream<1, 8, EPI_PART, 1> came out at 250 VGPRs + 64 AGPRs, one wave per SIMD, and the stream-batched
+        // draft lm_head took 48 us instead of 10 (profiles/r04_kernel_by_grid_throughput_b8.txt).  A k-step past the range
+        // re-requests the burst's first tile and is multiplied as zero.  The fused-epilogue instances compile well (78 + 8
+        // registers) and keep the branches: for them the seventh request costs the draft step 1.4-4.7 us (A/B on one box).
         const int rem = ks1 - ks;
-        u32x4 w[UNROLL > 1 ? UNROLL - 1 : 1][NTW];
-        u32x4 x[UNROLL > 1 ? UNROLL - 1 : 1][MT];
+        if constexpr (UNROLL >= 8 && EPI == EPI_PART) {
+            u32x4 w[UNROLL - 1][NTW];
+            u32x4 x[UNROLL - 1][MT];
 #pragma unroll
-        for (int u = 0; u < UNROLL - 1; ++u)
-            if (u < rem) {
+            for (int u = 0; u < UNROLL - 1; ++u) {
+                const int uu = u < rem ? u : 0;
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)u * 64);
+                for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)uu * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u) {
+                const int uu = u < rem ? u : 0;
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * xstep) : u32x4{0u, 0u, 0u, 0u};
+                    x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + uu * xstep) : u32x4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
-        for (int u = 0; u < UNROLL - 1; ++u)
-            if (u < rem) {
+            for (int u = 0; u < UNROLL - 1; ++u)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j)
+                for (int j = 0; j < NTW; ++j) {
+                    u32x4 wz = w[u][j];
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[j][t] = mfma16<H>(w[u][j], x[u][t], acc[j][t]);
-            }
+                    for (int q = 0; q < 4; ++q) wz[q] = u < rem ? wz[q] : 0u;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[j][t] = mfma16<H>(wz, x[u][t], acc[j][t]);
+                }
+        } else {
+            u32x4 w[UNROLL > 1 ? UNROLL - 1 : 1][NTW];
+            u32x4 x[UNROLL > 1 ? UNROLL - 1 : 1][MT];
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u)
+                if (u < rem) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) w[u][j] = __builtin_nontemporal_load(wp[j] + (size_t)u * 64);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        x[u][t] = mv[t] ? *reinterpret_cast<const u32x4 *>(xp[t] + u * xstep) : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u)
+                if (u < rem) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) acc[j][t] = mfma16<H>(w[u][j], x[u][t], acc[j][t]);
+                }
+        }
     }
     // Fold the 4 waves' accumulators through LDS, PT tiles at a time (a fold buffer for all NTW*MT tiles at once would be
     // 64 KiB at 4x4 and cap the kernel at two workgroups per CU), each step followed by its share of the epilogue.

@@ -197,7 +197,7 @@ __device__ __forceinline__ uint32_t wave_kth_largest(uint32_t mk, int k) {
 // works on <= 1024 candidates and scatters the <= k non-zero probabilities.
 // Per-row destinations of a batched launch (rows of different streams go to different arenas / token buffers),
 // passed by value; at most SD_NORM_BATCH rows per launch.
-#define SD_NORM_BATCH 16
+#define SD_NORM_BATCH 48
 struct NormTab {
     float *out[SD_NORM_BATCH];
     int *err[SD_NORM_BATCH];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NT) void norm_probs_kernel(const float *__restrict_
         samp_err = tab.samp_err[blockIdx.x];
     }
     const uint32_t neg_inf_key = 0x007fffffu;                     // fkey(-inf)
-    CandList *cl = (cl_out && !use_tab) ? cl_out + row : nullptr;
+    CandList *cl = cl_out ? cl_out + row : nullptr;
     if (cl && tid == 0) cl->n = -1;                               // (list mode below overwrites it)
 
     auto load_z = [&](int i) -> float {
@@ -1135,7 +1135,7 @@ static int launch_norm(const float *logits, int rows, int V, long ld_in, float t
     }
     // the head already left tile maxima and a cleared output row (EPI_HEAD): no candidate pass over V at all
     if (tile_max && !(top_k >= 1 && top_k <= 64 && temperature > 0.0f && (V & 15) == 0 && V >= 4096 && V <= 65536 &&
-                      (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && !use_tab && !filter_only))
+                      (ld_in & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && !filter_only))
         tile_max = nullptr;
     // two-kernel fast path: the row is cut over NB_SPLIT workgroups first (see norm_cand_kernel)
     CandRow *ws = nullptr;
@@ -1224,9 +1224,11 @@ extern "C" int sd_norm_sample(const float *logits, int V, float temperature, int
 
 // Batched rows: row r of `logits` (stride ld_in) is normalised into rows[r].probs_out; with `sample` each row also
 // draws its token (rows[r].tok_out) from its own noise / Philox stream.  Launches of at most SD_NORM_BATCH rows.
-extern "C" int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k,
-                             float top_p, int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace,
-                             void *stream) {
+// tile_max (or NULL): the head left the rows' tile maxima [n_rows][V / 16] and cleared the output rows (EPI_HEAD);
+// cand_lists (or NULL): one CandList per row comes back (the native lock-step loop's residual / bonus sample reads them).
+int sd_norm_batch_tiles(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k, float top_p,
+                        int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace, const float *tile_max,
+                        void *cand_lists, void *stream) {
     SD_REQUIRE(logits && rows && n_rows >= 0 && V > 0, "sd_norm_batch: bad arguments");
     SD_REQUIRE(temperature != 0.0f, "sd_norm_batch: temperature must be non-zero");
     for (int r0 = 0; r0 < n_rows; r0 += SD_NORM_BATCH) {
@@ -1243,10 +1245,18 @@ extern "C" int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in,
         char *ws = workspace ? static_cast<char *>(workspace) + (size_t)r0 * sizeof(CandRow) : nullptr;
         const int rc = launch_norm(logits + (size_t)r0 * ld_in, n, V, ld_in, temperature, top_k, top_p, bf16_round_logits,
                                    tab.out[0], 4, nullptr, sample != 0, nullptr, 0, 0, nullptr, nullptr,
-                                   aligned ? ws : nullptr, stream, &tab);
+                                   aligned ? ws : nullptr, stream, &tab, 0,
+                                   tile_max ? tile_max + (size_t)r0 * (size_t)(V >> 4) : nullptr,
+                                   cand_lists ? static_cast<CandList *>(cand_lists) + r0 : nullptr);
         if (rc != SD_OK) return rc;
     }
     return SD_OK;
+}
+extern "C" int sd_norm_batch(const float *logits, int n_rows, int V, long ld_in, float temperature, int top_k,
+                             float top_p, int bf16_round_logits, const sd_norm_row *rows, int sample, void *workspace,
+                             void *stream) {
+    return sd_norm_batch_tiles(logits, n_rows, V, ld_in, temperature, top_k, top_p, bf16_round_logits, rows, sample, workspace,
+                               nullptr, nullptr, stream);
 }
 
 static inline int mode_dt(int dtype_mode) { return (dtype_mode >> 4) & 3; }
@@ -1307,12 +1317,12 @@ int sd_resample_with_errors(const float *p_hist, const float *q_hist, long ld, i
 // slot i mod 1024, entries of one slot in index order, zeros adding nothing), block_sum and block_argmax are the same
 // device functions, and the Philox variates are drawn by token id.  Without a list (pl == NULL, or the row was not
 // produced in list mode) it runs resample_body's dense passes.
-__global__ __launch_bounds__(NT) void accept_resample_kernel(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
-                                                            long ld, int V, int32_t *__restrict__ seq, int L, int gamma,
-                                                            const float *__restrict__ r, uint64_t seed, uint64_t draw_scan,
-                                                            uint64_t draw_res, sd_accept_result *__restrict__ res,
-                                                            const int *__restrict__ err_flags, int n_err, int dt,
-                                                            const CandList *__restrict__ pl) {
+__device__ __forceinline__ void accept_resample_body(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
+                                                     long ld, int V, int32_t *__restrict__ seq, int L, int gamma,
+                                                     const float *__restrict__ r, uint64_t seed, uint64_t draw_scan,
+                                                     uint64_t draw_res, sd_accept_result *__restrict__ res,
+                                                     const int *__restrict__ err_flags, int n_err, int dt,
+                                                     const CandList *__restrict__ pl) {
     __shared__ SampleShared S;
     __shared__ float red[16];
     __shared__ float part[NT];
@@ -1415,6 +1425,24 @@ __global__ __launch_bounds__(NT) void accept_resample_kernel(const float *__rest
     }
 }
 
+__global__ __launch_bounds__(NT) void accept_resample_kernel(const float *__restrict__ p_hist, const float *__restrict__ q_hist,
+                                                            long ld, int V, int32_t *__restrict__ seq, int L, int gamma,
+                                                            const float *__restrict__ r, uint64_t seed, uint64_t draw_scan,
+                                                            uint64_t draw_res, sd_accept_result *__restrict__ res,
+                                                            const int *__restrict__ err_flags, int n_err, int dt,
+                                                            const CandList *__restrict__ pl) {
+    accept_resample_body(p_hist, q_hist, ld, V, seq, L, gamma, r, seed, draw_scan, draw_res, res, err_flags, n_err, dt, pl);
+}
+
+// The same for the streams of a lock-step iteration, one workgroup per stream (device Philox; lists[i] = the candidate
+// lists of stream i's gamma + 1 target rows, or NULL: that stream takes the dense passes).
+struct ListTab { const CandList *pl[SD_ACCEPT_BATCH]; };
+__global__ __launch_bounds__(NT) void accept_resample_batch_kernel(AcceptTab t, ListTab lt, long ld, int V, int gamma, int dt) {
+    const int i = blockIdx.x;
+    accept_resample_body(t.p_hist[i], t.q_hist[i], ld, V, t.seq[i], t.L[i], gamma, t.r[i], t.seed[i], t.draw_scan[i],
+                         t.draw_res[i], t.res[i], t.err_flags[i], t.n_err[i], dt, lt.pl[i]);
+}
+
 extern "C" int sd_accept_resample(const float *p_hist, const float *q_hist, long ld, int V, int32_t *seq, int L, int gamma,
                                   const float *r, uint64_t philox_seed, uint64_t draw_scan, uint64_t draw_resample,
                                   sd_accept_result *res, const int *err_flags, int n_err, int dtype_mode,
@@ -1450,6 +1478,29 @@ extern "C" int sd_multi_resample(const float *p_hist, const float *q_hist, long 
     SD_REQUIRE(p_hist && q_hist && seq && res && V > 0, "sd_multi_resample: bad arguments");
     hipLaunchKernelGGL(multi_resample_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, p_hist, q_hist, ld, V, seq,
                        gamma, exp_noise, philox_seed, draw_index, res, mode_dt(dtype_mode));
+    SD_LAUNCH_CHECK();
+    return SD_OK;
+}
+
+// The lock-step loop's accept scan + residual / bonus sample in ONE launch on the target rows' candidate lists
+// (accept_resample_body per stream; device Philox only - an item with exp_noise is refused).
+int sd_accept_resample_batch(const sd_accept_item *items, int n_items, long ld, int V, int gamma, int dtype_mode,
+                             const void *const *lists, void *stream) {
+    SD_REQUIRE(items && lists && n_items >= 1 && n_items <= SD_ACCEPT_BATCH, "sd_accept_resample_batch: 1..%d items", SD_ACCEPT_BATCH);
+    SD_REQUIRE(gamma >= 1 && gamma <= 16 && V > 0, "sd_accept_resample_batch: bad gamma / V");
+    AcceptTab t = {};
+    ListTab lt = {};
+    for (int i = 0; i < n_items; ++i) {
+        const sd_accept_item &it = items[i];
+        SD_REQUIRE(it.p_hist && it.q_hist && it.seq && it.res && it.L >= 1 && !it.exp_noise,
+                   "sd_accept_resample_batch: item %d: bad arguments", i);
+        t.p_hist[i] = it.p_hist; t.q_hist[i] = it.q_hist; t.seq[i] = it.seq; t.r[i] = it.r; t.noise[i] = nullptr;
+        t.res[i] = it.res; t.err_flags[i] = it.err_flags; t.n_err[i] = it.err_flags ? it.n_err : 0;
+        t.seed[i] = it.philox_seed; t.draw_scan[i] = it.draw_scan; t.draw_res[i] = it.draw_resample; t.L[i] = it.L;
+        lt.pl[i] = static_cast<const CandList *>(lists[i]);
+    }
+    hipLaunchKernelGGL(accept_resample_batch_kernel, dim3(n_items), dim3(NT), 0, (hipStream_t)stream, t, lt, ld, V, gamma,
+                       mode_dt(dtype_mode));
     SD_LAUNCH_CHECK();
     return SD_OK;
 }

@@ -193,6 +193,56 @@ def test_native_bf16_iteration_bit_equals_python_loop(hip, case, capsys):
         assert 0 < sum(da["acc_len"]) < 4 * len(da["acc_len"])   # partial accepts really occur
 
 
+@pytest.mark.parametrize("case", ["perturbed_g4", "all_accept_g4", "perturbed_g8_two_passes", "seeded_g2", "split_lm_head"])
+def test_stream_batched_bf16_fused_tail_bit_equals_the_dense_tail(hip, case):
+    """The lock-step loop's sampling tail (round 4): the draft head leaves tile maxima and clears the streams' probability
+    rows (EPI_HEAD with one pointer per stream), the norm + sample runs on them without a logits copy or a candidate pass,
+    the target rows come back with candidate lists and the accept scan + residual / bonus sample is ONE launch on them.
+    Against the round-1 tail (SD_BATCH_FUSED_TAIL=0: logits copy, norm_cand + norm_probs, dense accept scan + resample)
+    under the same Philox seeds every stream's tokens, accepted lengths and acceptance ratios must be bit-equal - bf16
+    weights, a vocabulary wide enough for the tile path, streams of different prompt lengths, one of which stops at EOS;
+    16 streams x 9 rows need two verify passes (the lists then stay off and the loop takes the dense accept)."""
+    cfg = ModelConfig(**BF16_CFG)
+    dsd = make_state_dict(cfg, 5, dtype=torch.bfloat16)
+    tsd = dsd if case.startswith("all_accept") else \
+        {k: v.to(torch.bfloat16) for k, v in perturb_state_dict({a: b.float() for a, b in dsd.items()}, 6, 0.05).items()}
+    dm = hip.engine.SpecDecModel.from_state_dict(cfg, dsd, dtype=torch.bfloat16)
+    tm = dm if case.startswith("all_accept") else hip.engine.SpecDecModel.from_state_dict(cfg, tsd, dtype=torch.bfloat16)
+    gamma = 8 if "g8" in case else (2 if "g2" in case else 4)
+    B = 16 if "two_passes" in case else 6
+    rng = np.random.default_rng(17)
+    prompts = [torch.from_numpy(rng.integers(3, cfg.vocab_size, size=(1, 5 + 7 * (i % 5)))).cuda() for i in range(B)]
+    seeds = [4100 + i for i in range(B)]
+    kw = dict(gamma=gamma, top_k=20, top_p=0.9)
+    if case == "seeded_g2":
+        kw["random_seed"] = 42
+    if case == "split_lm_head":
+        os.environ["SD_GEMM_UNITS"] = "1536"
+    try:
+        probe = hip.S.speculative_sampling_batch(prompts[1:2], dm, tm, -1, None, 24, seeds=seeds[1:2], **kw)
+        eos = int(probe[0][0, prompts[1].shape[1] + 5])
+        runs = {}
+        for mode in ("0", "1"):
+            os.environ["SD_BATCH_FUSED_TAIL"] = mode
+            runs[mode] = hip.S.speculative_sampling_batch(prompts, dm, tm, eos, None, 24, details=True, seeds=seeds, **kw)
+    finally:
+        os.environ.pop("SD_BATCH_FUSED_TAIL", None)
+        os.environ.pop("SD_GEMM_UNITS", None)
+    (o0, d0), (o1, d1) = runs["0"], runs["1"]
+    stopped = 0
+    for a, b, da, db, p in zip(o0, o1, d0, d1, prompts):
+        assert torch.equal(a, b), (a, b)
+        assert da["acc_len"] == db["acc_len"] and da["target_call_times"] == db["target_call_times"]
+        assert float(da["acc_rate"]) == float(db["acc_rate"])
+        stopped += a.shape[1] < p.shape[1] + 24
+    assert stopped >= 1
+    if case.startswith("all_accept"):
+        assert all(x == gamma for d in d1 for x in d["acc_len"])
+    if case.startswith("perturbed"):
+        tot = sum(sum(d["acc_len"]) for d in d1)
+        assert 0 < tot < gamma * sum(len(d["acc_len"]) for d in d1)
+
+
 # --------------------------------------------------------------------------- headline shapes vs the oracle
 def _host_sd(m):
     sd = {n: m._synth_get(n).cpu() for n in m._synth_names}
