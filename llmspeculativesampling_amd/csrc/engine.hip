@@ -153,7 +153,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 #define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
 #define SD_ROWS_MAX 144                              // rows the balanced one-workgroup-per-CU kernel covers (9 m-tiles: a 128-token prompt + gamma rows)
 struct EnvTun {
-    int gemm_ntw = 4, gemm_units = -1, small_path = 0, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
+    int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
@@ -162,7 +162,10 @@ static void refresh_env() {
     auto geti = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     g_env.gemm_ntw = geti("SD_GEMM_NTW", 4);
     g_env.gemm_units = geti("SD_GEMM_UNITS", -1);
-    g_env.small_path = geti("SD_SMALL_PATH", 0);      // off by default: measured slower than the per-op chain
+    // 1 (default since round 4): a small model's <= 4-row step runs the layers' two norm launches as prologues of QKV / gate-up
+    // (llama-68m 94.9 -> 92.3 us, opt-125m 426-440 -> 417 us per draft step); 2: every seam a prologue incl. the head (slower);
+    // 0: the per-op chain.  Rounds 2-4 measured the prologue route 75 % slower: that was a 254-VGPR compile of gemm_small
+    g_env.small_path = geti("SD_SMALL_PATH", 1);
     g_env.small_split_bytes = geti("SD_SMALL_SPLIT_BYTES", 0);
     g_env.fuse_embed_qkv = geti("SD_FUSE_EMBED_QKV", 1);
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
@@ -1091,6 +1094,49 @@ static int launch_gemm_fin(sd_session *s, const void *W, const void *X, int M, i
     return SD_OK;
 }
 
+// The lm_head over the (normalised, operand-layout) rows `hl`; xt (or NULL) maps logit row i to its row of hl.  Native
+// iteration: the head also leaves the maximum of every 16-column tile and clears the probability rows, so the
+// normalisation that follows needs no candidate pass over V (EPI_HEAD; whole k-range per workgroup).
+template <typename T>
+static int head_logits(sd_session *s, const T *hl, const RowTab *xt, int n_logits, float *logits_out, long ld_logits, hipStream_t st) {
+    using H16 = typename std::conditional<std::is_same<T, float>::value, bf16_t, T>::type;
+    sd_model *m = s->m;
+    const sd_model_config &c = m->cfg;
+    const int ED = embed_dim(c);
+    const bool llama = c.arch == SD_ARCH_LLAMA;
+    GemmOut go;
+    int rc;
+    const int round_t = (c.logits_bf16_round || !llama) ? round_code(c.dtype) : 0;
+    const bool zero_tab = !s->head_zero_rows && s->head_zero_n > 0 && s->head_zero_n == n_logits;
+    if (is16(c.dtype) && s->want_raw_logits && (s->head_zero_rows || zero_tab) && n_logits <= 16 && c.vocab % 16 == 0 &&
+        gemm_plan(c.vocab, ED, n_logits, false).S == 1 && !gemm_plan(c.vocab, ED, n_logits, false).tiled) {
+        GemmEpiT<H16> e = {};
+        if (xt) { e.use_xmap = 1; e.tab = *xt; }
+        e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
+        if (zero_tab)
+            for (int i = 0; i < n_logits; ++i) e.zero_ptr[i] = s->head_zero_ptr[i];
+        {
+            ProfScope ps(s, PC_GEMM, st);
+            launch_gemm_bf16<1, EPI_HEAD, 1, H16>(m->w.lm_head, (const H16 *)hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
+            SD_LAUNCH_CHECK();
+        }
+        s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
+        s->last_tile_max = s->tile_max;
+        return SD_OK;
+    }
+    if ((rc = run_gemm<H16>(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
+    if (s->want_raw_logits && go.S == 1) {
+        s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
+    } else {
+        ProfScope ps(s, PC_LOGITS, st);
+        hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
+                           go.stride_s, c.vocab, round_t, logits_out, ld_logits);
+        SD_LAUNCH_CHECK();
+        s->last_logits = logits_out; s->last_logits_ld = ld_logits; s->last_logits_round = 0;
+    }
+    return SD_OK;
+}
+
 // ---- small-model decode path (small_kernels.h): 5 launches per layer + the head --------------------------------
 static bool small_path_ok(const sd_session *s, const RowTab &tab) {
     const sd_model_config &c = s->m->cfg;
@@ -1143,6 +1189,9 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
     bf16_t *qb = (bf16_t *)s->qbuf, *at = (bf16_t *)s->attn, *ac = (bf16_t *)s->act;
     int cur = 0;                                                   // R[cur] holds the residual stream
     int rc;
+    // SD_SMALL_PATH=1: the two norm launches of a layer become prologues of QKV / gate-up; O, down and the head keep the
+    // per-op chain's kernels.  =2: every seam a prologue and gemm_small for O / down (the round-2 route, kept for A/B)
+    const bool all_pro = g_env.small_path >= 2;
     int S_o, ksp_o, S_d, ksp_d;
     small_split(H, q_dim(c), &S_o, &ksp_o);
     small_split(H, I, &S_d, &ksp_d);
@@ -1191,7 +1240,11 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
         {
             GemmEpi e = {};
             SmallPro p = {};
-            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wo[l], at, s->spart, M, H, q_dim(c), S_o, ksp_o, e, p, st)) != SD_OK) return rc;
+            // (the streaming kernel leaves the same slabs: [S][16][H], the same k-split, the same sums - and runs 0.1-0.9 us
+            //  faster than gemm_small<PRO_TILED> on these shapes)
+            if (all_pro) rc = launch_small<PRO_TILED, EPI_PART>(s, m->wo[l], at, s->spart, M, H, q_dim(c), S_o, ksp_o, e, p, st);
+            else { ProfScope ps(s, PC_GEMM, st); rc = dispatch_gemm_bf16<EPI_PART, bf16_t>(m->wo[l], at, s->spart, M, 16, H, q_dim(c), S_o, ksp_o, e, st); SD_LAUNCH_CHECK(); }
+            if (rc != SD_OK) return rc;
         }
         // ---- gate/up (fc1): prologue = O slabs + residual + post-attention norm; epilogue = SiLU * up / ReLU
         {
@@ -1207,12 +1260,27 @@ static int forward_small(sd_session *s, const RowTab &tab, int s_max, float *log
         {
             GemmEpi e = {};
             SmallPro p = {};
-            if ((rc = launch_small<PRO_TILED, EPI_PART>(s, m->wdown[l], ac, s->spart, M, H, I, S_d, ksp_d, e, p, st)) != SD_OK) return rc;
+            if (all_pro) rc = launch_small<PRO_TILED, EPI_PART>(s, m->wdown[l], ac, s->spart, M, H, I, S_d, ksp_d, e, p, st);
+            else { ProfScope ps(s, PC_GEMM, st); rc = dispatch_gemm_bf16<EPI_PART, bf16_t>(m->wdown[l], ac, s->spart, M, 16, H, I, S_d, ksp_d, e, st); SD_LAUNCH_CHECK(); }
+            if (rc != SD_OK) return rc;
         }
     }
     s->last_tile_max = nullptr;
+    if (n_logits > 0 && !all_pro) {
+        // ---- head: the final residual + norm keeps its launch.  As a prologue of the lm_head every one of its 2000-3142
+        // workgroups folds the slabs and normalises the rows for itself: 18.5 us against 4.4 + 9.6 on llama-68m, 31.4 against
+        // 4.3 + 14.2 on opt-125m (rocprofv3, profiles/r04_small_path_*.txt)
+        {
+            ProfScope ps(s, PC_NORM, st);
+            hipLaunchKernelGGL((residual_norm_kernel<bf16_t>), dim3(M), dim3(rn_threads), 0, st, R[cur], (const float *)s->spart, S_d,
+                               (size_t)16 * H, H, (const bf16_t *)m->bfc2[L - 1], (const bf16_t *)m->w.final_norm_w,
+                               (const bf16_t *)m->w.final_norm_b, c.norm_eps, norm_kind, (int)RES_PRE, (bf16_t *)s->h);
+            SD_LAUNCH_CHECK();
+        }
+        return head_logits<bf16_t>(s, (const bf16_t *)s->h, &tab, n_logits, logits_out, ld_logits, st);
+    }
     if (n_logits > 0) {
-        // ---- head: prologue = last down slabs + residual + final norm on the rows that need logits
+        // ---- head (SD_SMALL_PATH=2): prologue = last down slabs + residual + final norm on the rows that need logits
         GemmEpi e = {};
         e.use_xmap = 1; e.tab = tab;
         SmallPro p = resid_pro(S_d, (const bf16_t *)m->bfc2[L - 1], m->w.final_norm_w, m->w.final_norm_b, false);
@@ -1461,36 +1529,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             SD_LAUNCH_CHECK();
             hl = eb;
         }
-        const int round_t = (c.logits_bf16_round || !llama) ? round_code(c.dtype) : 0;
-        // native iteration: the head also leaves the maximum of every 16-column tile and clears the probability rows, so
-        // the normalisation that follows needs no candidate pass over V (EPI_HEAD; whole k-range per workgroup)
-        const bool zero_tab = !s->head_zero_rows && s->head_zero_n > 0 && s->head_zero_n == n_logits;
-        if (is16(c.dtype) && s->want_raw_logits && (s->head_zero_rows || zero_tab) && n_logits <= 16 && c.vocab % 16 == 0 &&
-            gemm_plan(c.vocab, ED, n_logits, false).S == 1 && !gemm_plan(c.vocab, ED, n_logits, false).tiled) {
-            GemmEpiT<H16> e = {};
-            if (xt) { e.use_xmap = 1; e.tab = *xt; }
-            e.tile_max = s->tile_max; e.zero_rows = s->head_zero_rows; e.zero_ld = s->head_zero_ld;
-            if (zero_tab)
-                for (int i = 0; i < n_logits; ++i) e.zero_ptr[i] = s->head_zero_ptr[i];
-            {
-                ProfScope ps(s, PC_GEMM, st);
-                launch_gemm_bf16<1, EPI_HEAD, 1, H16>(m->w.lm_head, hl, s->part, n_logits, 16, c.vocab, ED, 1, ED / 32, e, st);
-                SD_LAUNCH_CHECK();
-            }
-            s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
-            s->last_tile_max = s->tile_max;
-            return SD_OK;
-        }
-        if ((rc = run_gemm<H16>(s, m->w.lm_head, hl, n_logits, c.vocab, ED, &go, st, xt)) != SD_OK) return rc;
-        if (s->want_raw_logits && go.S == 1) {
-            s->last_logits = s->part; s->last_logits_ld = c.vocab; s->last_logits_round = round_t;
-        } else {
-            ProfScope ps(s, PC_LOGITS, st);
-            hipLaunchKernelGGL((logits_kernel<T>), dim3((c.vocab + 255) / 256, n_logits), dim3(256), 0, st, s->part, go.S,
-                               go.stride_s, c.vocab, round_t, logits_out, ld_logits);
-            SD_LAUNCH_CHECK();
-            s->last_logits = logits_out; s->last_logits_ld = ld_logits; s->last_logits_round = 0;
-        }
+        return head_logits<T>(s, hl, xt, n_logits, logits_out, ld_logits, st);
     }
     return SD_OK;
 }

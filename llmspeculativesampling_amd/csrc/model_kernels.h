@@ -351,7 +351,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_stream(const u32x4 *__restrict_
     constexpr int NP = NTW * MT;                                  // accumulator tiles per wave
     constexpr int PT = NP % 4 == 0 ? 4 : (NP % 2 == 0 ? 2 : 1);    // of which PT go through the LDS fold per step
     __shared__ f32x4 red[4][PT][64];
+    // (the wave id as a SCALAR: with `threadIdx.x >> 6` the k-range bounds look per-lane to hipcc, the k-loops become
+    //  exec-masked loops and the accumulators are kept twice - main loop and tail - in AGPRs: <3, 2, ., 4> 78 + 96 registers
+    //  against 76 + 48 with the scalar id, two waves per SIMD against four)
+#ifndef SD_STREAM_VECTOR_WV
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#endif
     const int NTG = (N >> 4) / NTW, KS = K >> 5;
     const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
     const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_stream_w16(const u32x4 *__r
                                                               int K, GemmEpiT<H> e) {
     constexpr int U = 4;                                          // (NW = 16, or 8 for matrices with a few hundred n-tiles)
     __shared__ f32x4 red[NW][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int KS = K >> 5, ntg = blockIdx.x;
     const int per = (KS + NW - 1) / NW;
     const int ks0 = min(KS, wv * per), ks1 = min(KS, ks0 + per), ksa = min(ks0, KS - 1);
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tiled(const u32x4 *__restrict__
     constexpr int LPT = (NL + 3) / 4;                             // tile loads per wave per k-step
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     u32x4 (*sm)[NL][64] = reinterpret_cast<u32x4 (*)[NL][64]>(dyn_smem);          // [2][NL][64]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wn = wv & 1, wm = wv >> 1;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wn = wv & 1, wm = wv >> 1;
     const int KS = K >> 5, NB = (N >> 4) / WT, MB = ((Mpad >> 4) + XT - 1) / XT;
     int b = blockIdx.x;
     const int mb = b % MB; b /= MB;                               // m-blocks of one n-block are neighbours (W reuse in L2)

@@ -47,20 +47,27 @@ __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, 
     __shared__ f32x4 red[4][1][64];
     extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
     bf16_t *Xs = reinterpret_cast<bf16_t *>(dyn_smem);           // [M][K + SMALL_XPAD]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTG = N >> 4, KS = K >> 5;
     const int sb = blockIdx.x / NTG, ntg = blockIdx.x - sb * NTG;
     const int kb0 = sb * ks_per_blk, kb1 = min(KS, kb0 + ks_per_blk);
     const int per = (kb1 - kb0 + 3) >> 2;
     const int ks0 = min(kb1, kb0 + wv * per), ks1 = min(kb1, ks0 + per);
-    const u32x4 *wp = Wp + ((size_t)ntg * KS + ks0) * 64 + lane;
+    const u32x4 *wt = Wp + (size_t)ntg * KS * 64 + lane;          // this n-tile's k-step 0
     const int mrow = lane & 15, kq = (lane >> 4) * 8;
     const bool mv = mrow < M;
 
+    // No branch around a load or an MFMA in this kernel.  With `if (ks < ks1)` around each of the KSW requests and
+    // multiplications (per-lane-looking bounds: wv was tid >> 6) hipcc built divergent-branch ladders: the PRO_RESID
+    // instances with the SiLU / ReLU / head / slab epilogues and PRO_TILED + slab came out at 254 VGPRs + 44 AGPRs, one
+    // wave per SIMD (-Rpass-analysis=kernel-resource-usage), which is what rounds 2-4 measured as "the prologue route is
+    // slower" (gate/up 15.9 us, lm_head 48 us).  Here a k-step past the wave's range re-requests k-step `kc` (clamped into
+    // the matrix) and meets a zeroed weight fragment; the wave id is scalar, so the loop bounds are too.
+    auto kc = [&](int ks) { return min(max(ks, 0), KS - 1); };
     // the weights do not depend on the prologue: request this wave's first KSW tiles now
     u32x4 w[KSW];
 #pragma unroll
-    for (int u = 0; u < KSW; ++u) w[u] = ks0 + u < ks1 ? __builtin_nontemporal_load(wp + (size_t)u * 64) : u32x4{0u, 0u, 0u, 0u};
+    for (int u = 0; u < KSW; ++u) w[u] = __builtin_nontemporal_load(wt + (size_t)kc(min(ks0 + u, ks1 - 1)) * 64);
 
     if constexpr (PRO == PRO_EMBED) {
         // embed_norm_kernel's arithmetic: thread t owns columns t, t + 256, ...
@@ -172,33 +179,31 @@ __global__ __launch_bounds__(256) void gemm_small(const u32x4 *__restrict__ Wp, 
     // ---- the dot products: B fragment = X[m = lane & 15][32 * ks + 8 * (lane >> 4) .. + 8)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16_t *xg = nullptr;
+    // rows >= M read row 0's operand (finite values; their output columns are dropped by the epilogue)
+    const int mr = mv ? mrow : 0;
     if constexpr (PRO == PRO_TILED) {
-        const int msrc = mv ? (e.use_xmap ? (int)e.tab.xmap[mrow] : mrow) : 0;
-        xg = X + ((size_t)(msrc >> 4) * KS + ks0) * 512 + ((lane >> 4) * 16 + (msrc & 15)) * 8;
+        const int msrc = e.use_xmap ? (int)e.tab.xmap[mr] : mr;
+        xg = X + (size_t)(msrc >> 4) * KS * 512 + ((lane >> 4) * 16 + (msrc & 15)) * 8;
     }
     for (int base = ks0; base < ks1; base += KSW) {
         if (base != ks0) {
 #pragma unroll
-            for (int u = 0; u < KSW; ++u)
-                if (base + u < ks1) w[u] = __builtin_nontemporal_load(wp + (size_t)(base - ks0 + u) * 64);
+            for (int u = 0; u < KSW; ++u) w[u] = __builtin_nontemporal_load(wt + (size_t)kc(min(base + u, ks1 - 1)) * 64);
         }
         u32x4 x[KSW];
 #pragma unroll
         for (int u = 0; u < KSW; ++u) {
-            x[u] = u32x4{0u, 0u, 0u, 0u};
-            if (base + u < ks1) {
-                if constexpr (PRO == PRO_TILED)
-                    x[u] = mv ? *reinterpret_cast<const u32x4 *>(xg + (size_t)(base - ks0 + u) * 512) : u32x4{0u, 0u, 0u, 0u};
-                else
-                    x[u] = mv ? *reinterpret_cast<const u32x4 *>(Xs + (size_t)mrow * (K + SMALL_XPAD) + (base + u) * 32 + kq)
-                              : u32x4{0u, 0u, 0u, 0u};
-            }
+            const int ks = kc(min(base + u, ks1 - 1));
+            if constexpr (PRO == PRO_TILED) x[u] = *reinterpret_cast<const u32x4 *>(xg + (size_t)ks * 512);
+            else x[u] = *reinterpret_cast<const u32x4 *>(Xs + (size_t)mr * (K + SMALL_XPAD) + ks * 32 + kq);
         }
 #pragma unroll
-        for (int u = 0; u < KSW; ++u)
-            if (base + u < ks1)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[u]),
-                                                              __builtin_bit_cast(bf16x8, x[u]), acc, 0, 0, 0);
+        for (int u = 0; u < KSW; ++u) {
+            u32x4 wz = w[u];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wz[q] = base + u < ks1 ? wz[q] : 0u;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wz), __builtin_bit_cast(bf16x8, x[u]), acc, 0, 0, 0);
+        }
     }
     red[wv][0][lane] = acc;
     __syncthreads();

@@ -504,8 +504,10 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     ids = torch.from_numpy(np.random.default_rng(19).integers(3, cfg.vocab_size, size=(1, 41))).to(torch.int32).cuda()[0]
     outs = {}
     modes = {"per_op": {"SD_SMALL_PATH": "0", "SD_FUSE_EMBED_QKV": "0"},      # one launch per op (the round-1 chain)
-             "default": {},                                                    # embedding + norm fused into QKV(0)
-             "1": {"SD_SMALL_PATH": "1"}}                                     # every norm fused into its consumer
+             "default": {"SD_SMALL_PATH": "0"},                                # (round 3's default) embedding + norm fused into QKV(0)
+             "1": {"SD_SMALL_PATH": "2"},                                     # every norm fused into its consumer
+             "hybrid": {}}                                                    # (the default) the layers' norms as QKV / gate-up prologues;
+                                                                               # O, down and the head on the per-op kernels
     for flag, env in modes.items():
         os.environ.update(env)
         try:
@@ -522,12 +524,14 @@ def test_small_model_path_is_bit_identical_to_the_launch_per_op_chain(hip, name)
     outs["0"] = outs["per_op"]
     # the DEFAULT route (per-op chain + embedding / first norm fused into the layer-0 QKV GEMM) is bit-identical at any V
     assert torch.equal(outs["default"][0], outs["0"][0]) and torch.equal(outs["default"][1], outs["0"][1])
-    # SD_SMALL_PATH=1 (off by default): every K / V row is bit-identical; so are the logits once the per-op head keeps the
+    # SD_SMALL_PATH=2 (every seam a prologue): every K / V row is bit-identical; so are the logits once the per-op head keeps the
     # whole k-range too (>= 1024 n-tiles).  Below that the two heads add the same products in a different fp32 order, and a
     # logit may land on the other side of a bf16 rounding boundary: never by more than one bf16 ulp, and no NaN (the
     # hidden-256 case has waves with an empty k-range: DESIGN.md section 7, "uninitialised MFMA operand")
     assert not bool(torch.isnan(outs["1"][0]).any()) and not bool(torch.isnan(outs["1"][1].float()).any())
     assert torch.equal(outs["1"][1], outs["0"][1])
+    # SD_SMALL_PATH=1 (round 4): the head is the per-op chain's own, so the logits are bit-identical at any vocabulary size
+    assert torch.equal(outs["hybrid"][1], outs["0"][1]) and torch.equal(outs["hybrid"][0], outs["0"][0])
     if cfg.vocab_size >= 16384:
         assert torch.equal(outs["1"][0], outs["0"][0])
     else:
