@@ -22,7 +22,11 @@ timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --out
 fm=$(find $O/pmc_mfma8 -name "*counter_collection.csv" | head -1); python tools/pmc_mfma.py $fm > $O/pmc_mfma_throughput_b8.json 2> $O/pmc_mfma_b8.err; rm -rf $O/pmc_mfma8
 echo "[8] throughput by grid"; timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/profb -o b8 -- python3 bench.py --steps 1 --warmup 1 --cpu-baseline 0 --accept-sweep 0 --batch-streams 8 --profile-classes 0 > /dev/null 2>&1
 t=$(find $O/profb -name "*kernel_trace.csv" | head -1); python tools/trace_by_grid.py $t > $O/kernel_by_grid_throughput_b8.txt 2>&1; rm -rf $O/profb
-echo "[9] draft step"; timeout -k 10 200 python tools/draft_step_bench.py > $O/draft_step_bench.txt 2>&1
+echo "[9] draft step"; timeout -k 10 200 python tools/draft_step_bench.py - SD_SMALL_PATH=0 SD_SMALL_PATH=2 > $O/draft_step_bench.txt 2>&1
+timeout -k 10 200 python tools/draft_step_bench.py --draft opt-125m - SD_SMALL_PATH=0 SD_SMALL_PATH=2 >> $O/draft_step_bench.txt 2>&1
+echo "[9b] lock-step tail A/B"; for mode in 0 1; do SD_BATCH_FUSED_TAIL=$mode timeout -k 10 300 python bench.py --steps 1 --warmup 1 $B --batch-streams 8 > $O/bench_throughput_b8_tail$mode.json 2>/dev/null; done
+echo "[9c] tp shard"; timeout -k 10 300 python tools/tp_shard_bench.py > $O/tp8_shard_one_gpu.txt 2>&1
+echo "[9d] small-path by grid"; bash tools/trace_cmd.sh r04/small_path_llama68m - tools/draft_step_bench.py --max-len 64 > /dev/null 2>&1; bash tools/trace_cmd.sh r04/small_path_opt125m - tools/draft_step_bench.py --draft opt-125m --max-len 64 > /dev/null 2>&1
 echo "[10] 70b"; timeout -k 10 500 python bench.py --target llama-2-70b --kv-dtype fp8 --steps 2 $B > $O/bench_llama70b_fp8kv_1gpu.json 2>/dev/null
 echo "[11] rows"; timeout -k 10 300 python tools/forward_rows_bench.py 5 9 16 40 64 72 127 132 256 > $O/forward_rows.txt 2>&1
 ls -la $O
