@@ -153,7 +153,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 #define SD_STREAM_MAX_ROWS 64                        // rows the streaming kernel's m-tile variants cover
 #define SD_ROWS_MAX 144                              // rows the balanced one-workgroup-per-CU kernel covers (9 m-tiles: a 128-token prompt + gamma rows)
 struct EnvTun {
-    int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, fuse_embed_qkv = 1, head_tiles = 1;
+    int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, tiny_split_bytes = 24576, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
@@ -167,6 +167,7 @@ static void refresh_env() {
     // 0: the per-op chain.  Rounds 2-4 measured the prologue route 75 % slower: that was a 254-VGPR compile of gemm_small
     g_env.small_path = geti("SD_SMALL_PATH", 1);
     g_env.small_split_bytes = geti("SD_SMALL_SPLIT_BYTES", 0);
+    g_env.tiny_split_bytes = geti("SD_TINY_SPLIT_BYTES", 24576);   // k-slab size of <= 16-row GEMMs on matrices of <= 8 MB (0: the big-matrix policy)
     g_env.fuse_embed_qkv = geti("SD_FUSE_EMBED_QKV", 1);
     g_env.head_tiles = geti("SD_HEAD_TILES", 1);
     g_env.attn_split_keys = geti("SD_ATTN_SPLIT_KEYS", 384);          // keys per workgroup above which a group's keys are split
@@ -221,6 +222,13 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
             const double cost = (wbytes + slab * c) / eff * (blocks < 768 ? 1.25 : 1.0);   // too few workgroups under-fill the load path
             if (cost < best) { best = cost; S = c; }
         }
+    } else if ((size_t)N * K * 2 <= ((size_t)8 << 20) && g_env.tiny_split_bytes > 0) {
+        // a matrix of a small model (the draft's O / down projection: 1.2 / 4.7 MB): its launch is latency, not bytes, and
+        // every slab is another 16-byte load per column group in the consumer's fold - so few slabs, each workgroup streaming
+        // about tiny_split_bytes (24 KiB: down 12 -> 4 slabs, O 3 -> 1; on one box llama-68m / opt-125m steps of 91.5 / 415.4 us
+        // with the big-matrix policy, 87.3 / 387.6 at 24 KiB, 89.4 / 397.0 at 32, 90.2 / 402.5 at 48, 93.7 / 420.7 at 96 -
+        // tools/draft_step_bench.py SD_TINY_SPLIT_BYTES=...)
+        S = (int)((K * 32 + g_env.tiny_split_bytes / 2) / g_env.tiny_split_bytes);
     } else if (NTL < 1024) {
         // fewest slabs that give >= 1024 workgroups, preferring a workgroup count that fills all 256 CUs evenly
         // (measured on MI355X: 7.5 workgroups per CU runs 10 % slower than 15 per CU, tools/gemm_bench.py)
