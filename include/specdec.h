@@ -400,7 +400,12 @@ int sd_spec_generate(sd_spec *sp, int32_t *host_seq, int *len_io, int T, int eos
  * (lengths, cache lengths, Philox position); per-iteration statistics as in sd_spec_generate.  Each stream runs exactly
  * the algorithm of sd_spec_generate with its own Philox stream.  verify_ms_out / verify_streams_out / verify_ctx_out
  * (host, max_iters_log entries, may be NULL): time of each iteration's verify passes, streams in it, their mean context.
- * *err_out: 1 when a stream hit a sampling / normalisation error (the reference raises). */
+ * *err_out: 1 when a stream hit a sampling / normalisation error (the reference raises).
+ * norm_workspace (device, may be NULL): sd_norm_workspace_bytes(max_rows_per_forward) bytes - the candidate rows of a pass and,
+ * behind them, one candidate list per row.  With it the loop runs the single-stream loop's sampling tail (since round 4):
+ * the draft head leaves tile maxima and clears the streams' probability rows, the target rows come back with candidate
+ * lists, accept scan + residual / bonus sample are one launch on them - bit-equal to the dense kernels named above, which
+ * remain the path without a workspace, with more streams than one verify pass holds, and under SD_BATCH_FUSED_TAIL=0. */
 typedef struct {
     sd_session *draft, *target;
     int32_t *seq;
