@@ -12,6 +12,7 @@
 #include "model_kernels.h"
 #include "small_kernels.h"
 #include "rows_kernels.h"
+#include "mm_kernels.h"
 #include "fused_kernels.h"
 #include "normload_kernels.h"
 
@@ -155,6 +156,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, tiny_split_bytes = 24576, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
+    int gemm_mm = 1, mm_mtw = 0, mm_s = 0, mm_nt = 1;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
@@ -177,6 +179,10 @@ static void refresh_env() {
     g_env.ao_gap = geti("SD_AO_GAP", 100);            // ... and pause after every 8 requests
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
+    g_env.gemm_mm = geti("SD_GEMM_MM", 1);            // 1 (default): prefill passes the balanced kernel does not take run on gemm_bf16_mm (mm_kernels.h) instead of gemm_bf16_tiled
+    g_env.mm_mtw = geti("SD_MM_MTW", 0);              // (sweeps) m-tiles per wave of gemm_bf16_mm: 2 = 128-row blocks, 4 = 256-row blocks; 0 = by row count
+    g_env.mm_s = geti("SD_MM_S", 0);                  // (sweeps) k-slabs of gemm_bf16_mm; 0 = planned
+    g_env.mm_nt = geti("SD_MM_NT", 1);                // (sweeps) non-temporal weight tiles where a block holds all rows
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
     g_env.wide_qkv = geti("SD_WIDE_QKV", 1);          // 0: a QKV projection with <= 128 n-tiles keeps one 4-wave workgroup per tile (A/B, compare tests)
     g_env.tp_one_slab = geti("SD_TP_ONE_SLAB", 1);    // 0: a shard's O / down projection keeps its k-slabs + the fold launch in front of the all-reduce (A/B)
@@ -256,7 +262,7 @@ static void gemm_split(int N, int K, int M, int *S_out, int *ks_per_out) {
 // fuses them, and the whole forward comes out even (bench.py --batch-streams 8 / 12), so those stay on the streaming
 // kernel.  Slab count: about 480 workgroups (measured optimum for all four shapes at 64, 128 and 256 rows).
 #define SD_MAX_FWD_ROWS 256
-struct GemmPlan { bool tiled; int S, ksp, mtw; };
+struct GemmPlan { bool tiled; int S, ksp, mtw, mm; };
 struct RowsPlan { bool ok; int S, ksp, NG, grid, nwn, nwk, nld; };
 static RowsPlan rows_plan(int N, int K, int M, bool fused);
 // fused: the caller wants the GEMM's whole k-range per workgroup (QKV / activation epilogue inside the launch)
@@ -269,6 +275,25 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
     const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= g_env.rows_max && rows_plan(N, K, M, fused).ok;
     if (x_tiled && M >= tiled_min && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
         p.tiled = true;
+        if (g_env.gemm_mm && Mpad > 64) {
+            // gemm_bf16_mm (mm_kernels.h): 256-row blocks (mtw 4) or 128-row blocks (mtw 2) x 128 columns.  Fused (the caller
+            // wants the whole k-range per block for a QKV / activation epilogue): the block shape that fills the CUs better
+            // (13b at 256 rows: gate/up 216 blocks of 256 rows, QKV 240 blocks of 128).  Otherwise 256-row blocks past 128
+            // rows and k-slabs for about one block per CU (tools/mm_bench.py: O / down 6 slabs, QKV 2).
+            const int G = g_env.cus > 0 ? g_env.cus : 256, NB = N / 16 / 8;
+            auto blocks_of = [&](int mtw) { const int BMT = 4 * mtw; return ((Mpad / 16 + BMT - 1) / BMT) * NB; };
+            auto fill = [&](int blocks) { return (double)blocks / (double)(((blocks + G - 1) / G) * G); };
+            p.mm = 1;
+            p.mtw = Mpad <= 128 ? 2 : 4;
+            if (fused && Mpad > 128 && fill(blocks_of(2)) > fill(blocks_of(4)) + 0.05) p.mtw = 2;
+            if (g_env.mm_mtw) p.mtw = g_env.mm_mtw;
+            const int blocks = blocks_of(p.mtw);
+            int S = fused ? 1 : (g_env.mm_s ? g_env.mm_s : std::max(1, (G - G / 16 + blocks / 2) / blocks));
+            S = std::min(S, std::max(1, KS / 8));
+            p.ksp = (int)align_up((KS + S - 1) / S, 2);
+            p.S = (KS + p.ksp - 1) / p.ksp;
+            return p;
+        }
         p.mtw = Mpad <= 64 ? 2 : 4;
         const int MB = (Mpad / 16 + 2 * p.mtw - 1) / (2 * p.mtw), blocks = MB * (N / 16 / 8);
         int S = std::max(1, (480 + blocks / 2) / blocks);
@@ -281,9 +306,39 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
     return p;
 }
 
+// can a GEMM with this plan run a fused QKV / activation epilogue?  (the streaming and balanced kernels: always, with
+// SB = 1; the LDS-tiled kernel: never; gemm_bf16_mm: with one slab)
+static bool fused_plan_ok(const GemmPlan &p) { return !p.tiled || (p.mm && p.S == 1); }
+
+// gemm_bf16_mm (mm_kernels.h): EPI != EPI_PART needs pl.S == 1 (the block holds the whole k-range)
+template <int EPI, typename H = bf16_t>
+static void launch_gemm_mm(const void *W, const void *X, float *part, int M, int Mpad, int N, int K, const GemmPlan &pl,
+                           const GemmEpiT<H> &e, hipStream_t st) {
+    const int BMT = 4 * pl.mtw, MB = (Mpad / 16 + BMT - 1) / BMT, NB = N / 16 / 8;
+    const dim3 grid(MB * NB * pl.S);
+    const size_t lds = (size_t)3 * (8 + BMT) * 2 * 1024;          // NBUF = 3 stages x KT = 2 k-tiles x (8 W + BMT X) KiB
+    auto go = [&](auto kern) {
+        static bool attr = false;                                 // (one flag per instantiation of this lambda = per kernel)
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(MM_THREADS), lds, st, (const u32x4 *)W, (const u32x4 *)X, part, M, Mpad, N, K, pl.S,
+                           pl.ksp, e);
+    };
+    // 256-row blocks hold every row of a pass (<= 256 rows): their weight tiles are read once chip-wide -> non-temporal
+    if (pl.mtw == 2) go(gemm_bf16_mm<2, EPI, H, false>);
+    else go(gemm_bf16_mm<4, EPI, H, true>);
+}
+
 template <typename H = bf16_t>
 static void launch_gemm_tiled(const void *W, const void *X, float *part, int M, int Mpad, int N, int K,
                               const GemmPlan &pl, hipStream_t st) {
+    if (pl.mm) {
+        GemmEpiT<H> e0 = {};
+        launch_gemm_mm<EPI_PART, H>(W, X, part, M, Mpad, N, K, pl, e0, st);
+        return;
+    }
     const int MB = (Mpad / 16 + 2 * pl.mtw - 1) / (2 * pl.mtw), NB = N / 16 / 8;
     const dim3 grid(MB * NB * pl.S);
     const size_t lds = (size_t)2 * (8 + 2 * pl.mtw) * 2 * 1024;   // 2 buffers x (8 W + 2*MTW X tiles) x KT = 2 k-tiles
@@ -941,6 +996,15 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
             return SD_OK;
         }
     }
+    // a prefill pass past the balanced kernel's row count: gemm_bf16_mm with the epilogue on its accumulators
+    if (!e.use_xmap && !e.x_rowmajor) {
+        const GemmPlan pl = gemm_plan(N, K, M, true, true);
+        if (pl.tiled && pl.mm && pl.S == 1) {
+            launch_gemm_mm<EPI, H>(W, X, nullptr, M, Mpad, N, K, pl, e, st);
+            SD_LAUNCH_CHECK();
+            return SD_OK;
+        }
+    }
     // (eight waves per tile for a shard's gate/up - 448 n-tiles - measured slower: 5.94 against 5.86 ms per verify)
     const RowsPlan rp = (e.use_xmap || e.x_rowmajor) ? RowsPlan{} : rows_plan(N, K, M, true);
     const int rc = rp.ok ? launch_gemm_rows<EPI, H>(W, X, nullptr, M, Mpad, N, K, rp, e, st)
@@ -1417,7 +1481,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                 if ((rc = launch_gemm_xn<EPI_QKV_ROPE, H16>(s, m->wqkv[l], h, n_new, qkv_cols(c), H, m->n1w[l], c.norm_eps, e, st)) != SD_OK)
                     return rc;
             }
-        } else if (fused && !gemm_plan(qkv_cols(c), H, n_new, true, true).tiled) {
+        } else if (fused && fused_plan_ok(gemm_plan(qkv_cols(c), H, n_new, true, true))) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)qb; e.bias = (const H16 *)m->bqkv[l];
             e.cos_t = (const H16 *)m->w.rope_cos; e.sin_t = (const H16 *)m->w.rope_sin;
@@ -1482,7 +1546,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
             }
         }
         if (xn_o) {
-        } else if (fused && !gemm_plan(gu_cols(c), H, n_new, true, true).tiled) {
+        } else if (fused && fused_plan_ok(gemm_plan(gu_cols(c), H, n_new, true, true))) {
             GemmEpiT<H16> e = {};
             e.out = (H16 *)ac; e.bias = (const H16 *)m->bfc1[l]; e.n_out = I;
             rc = llama ? run_gemm_fused<EPI_ACT_SILU, H16>(s, m->wgu[l], h, n_new, gu_cols(c), H, e, st)

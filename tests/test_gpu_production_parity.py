@@ -449,3 +449,73 @@ def test_fp16_many_row_passes_13b_layer_shape_vs_oracle(hip):
     ok, ov = past[1]
     assert float((k.float().cpu() - ok.float()).abs().max()) <= 0.01 * max(1.0, float(ok.float().abs().max()))
     assert float((v.float().cpu() - ov.float()).abs().max()) <= 0.01 * max(1.0, float(ov.float().abs().max()))
+
+
+def _opt13b_layers(depth):
+    return ModelConfig(arch="opt", vocab_size=50272, hidden_size=5120, ffn_dim=20480, num_hidden_layers=depth,
+                       num_attention_heads=40, num_key_value_heads=40, max_position_embeddings=512, do_layer_norm_before=True)
+
+
+@pytest.mark.parametrize("arch,rows", [("llama", 256), ("llama", 200), ("llama", 150), ("opt", 256), ("opt", 177)],
+                         ids=["llama256", "llama200", "llama150", "opt256", "opt177"])
+def test_prefill_pass_on_gemm_bf16_mm_vs_fp32_truth(hip, arch, rows):
+    """Prefill passes past the balanced kernel's row count (145..256 rows) run their GEMMs on gemm_bf16_mm (mm_kernels.h: LDS-DMA
+    stages, two in flight across one barrier per 64 columns of K, staggered wave halves) - QKV and gate/up (fc1) with the fused
+    RoPE / KV-append and SiLU (ReLU + bias) epilogues on the block's accumulators, O / down (fc2) as k-slabs - at Llama-2-13b's
+    and opt-13b's layer shapes, 2 layers, for full (256), ragged (200, 177) and barely-past-144 (150) row counts: ONE pass over
+    `rows` prompt tokens, the logits of its last 8 rows under the file's rule (HIP error against the fp32 truth <= 1.5x the
+    reference-bf16's own), the last layer's K / V rows within the bf16 bar of the oracle's, and the launch classes: no
+    stand-alone QKV / activation epilogue launch is left in the pass."""
+    cfg = _llama13b_layers(2) if arch == "llama" else _opt13b_layers(2)
+
+    def soft_head(name, t):                                       # (OPT's tied head: see test_opt13b_config3_...)
+        return t * 0.0625 if name.endswith("embed_tokens.weight") else t
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=31, dtype=torch.bfloat16, max_pos=320, transform=soft_head if arch == "opt" else None)
+    sd16 = _host_sd(m)
+    ids = torch.from_numpy(np.random.default_rng(rows).integers(3, cfg.vocab_size, size=(1, rows)))
+    ses = m.new_session(320)
+    ses.profile(True)
+    got = ses.forward(ids[0].to(torch.int32).cuda(), 8).cpu()
+    prof = ses.profile_read()
+    ses.profile(False)
+    assert "qkv_rope_append" not in prof and "activation" not in prof, prof
+    k_hip, v_hip = (t.float().cpu() for t in ses.past_key_values()[1])
+    del ses, m
+    torch.cuda.empty_cache()
+    o16 = oracle.RefCausalLM(cfg, sd16)
+    r16 = o16(ids)
+    ref16 = r16.logits.float()[0, -8:]
+    k_ref, v_ref = (t.float() for t in r16.past_key_values[1])
+    del o16, r16
+    o32 = oracle.RefCausalLM(cfg, {k: v.float() for k, v in sd16.items()})
+    truth = o32(ids).logits.float()[0, -8:]
+    del o32
+    e_hip, e_ref = float((got - truth).abs().max()), float((ref16 - truth).abs().max())
+    rms_hip, rms_ref = float((got - truth).pow(2).mean().sqrt()), float((ref16 - truth).pow(2).mean().sqrt())
+    print(f"{arch} 13b shape, one {rows}-row pass: max err hip {e_hip:.4f} ref-bf16 {e_ref:.4f}; rms hip {rms_hip:.5f} ref-bf16 {rms_ref:.5f}")
+    _assert_within_reference_error((e_hip, e_ref, rms_hip, rms_ref), f"{arch}, {rows}-row pass")
+    for name, a, b in (("K", k_hip, k_ref), ("V", v_hip, v_ref)):
+        assert a.shape[2] >= rows
+        d = float((a[:, :, :rows] - b[:, :, :rows]).abs().max())
+        assert d <= 0.04 * max(1.0, float(b.abs().max())), (name, d)
+
+
+def test_prefill_pass_fp16_on_gemm_bf16_mm_vs_oracle(hip):
+    """The fp16 instances (v_mfma_f32_16x16x32_f16) of gemm_bf16_mm: a 256-row and a 170-row pass of ONE sequence at the 13b
+    layer shape against the oracle's fp16 forward (what evaluation.py:185 loads), last five logit rows within fp16's bar."""
+    cfg = _llama13b_layers(2)
+    m = hip.engine.SpecDecModel.synthetic(cfg, seed=13, dtype=torch.float16, max_pos=448, gain=0.5)
+    om = oracle.RefCausalLM(cfg, _host_sd(m))
+    ses = m.new_session(448)
+    ids = torch.from_numpy(np.random.default_rng(23).integers(3, cfg.vocab_size, size=(1, 426)))
+    past, pos = None, 0
+    for q in (256, 170):
+        chunk = ids[:, pos:pos + q]
+        o = om(chunk, past_key_values=past)
+        past = o.past_key_values
+        got = ses.forward(chunk[0].to(torch.int32).cuda(), 5).cpu()
+        want = o.logits.float()[0, -5:]
+        scale, err = float(want.abs().max()), float((got - want).abs().max())
+        print(f"fp16, {q}-row pass at position {pos}: |logit| max {scale:.2f}, max err {err:.4f}")
+        assert err <= 0.005 * scale + 2e-3, (q, err, scale)
+        pos += q
