@@ -156,7 +156,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, tiny_split_bytes = 24576, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_mm = 1, mm_mtw = 0, mm_s = 0, mm_nt = 1;
+    int gemm_mm = 1, mm_mtw = 0, mm_s = 0;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
@@ -182,7 +182,7 @@ static void refresh_env() {
     g_env.gemm_mm = geti("SD_GEMM_MM", 1);            // 1 (default): prefill passes the balanced kernel does not take run on gemm_bf16_mm (mm_kernels.h) instead of gemm_bf16_tiled
     g_env.mm_mtw = geti("SD_MM_MTW", 0);              // (sweeps) m-tiles per wave of gemm_bf16_mm: 2 = 128-row blocks, 4 = 256-row blocks; 0 = by row count
     g_env.mm_s = geti("SD_MM_S", 0);                  // (sweeps) k-slabs of gemm_bf16_mm; 0 = planned
-    g_env.mm_nt = geti("SD_MM_NT", 1);                // (sweeps) non-temporal weight tiles where a block holds all rows
+
     g_env.gemm_rows = geti("SD_GEMM_ROWS", 1);        // 0: 17..64-row GEMMs stay on the streaming kernel (A/B runs, bit-compare tests)
     g_env.wide_qkv = geti("SD_WIDE_QKV", 1);          // 0: a QKV projection with <= 128 n-tiles keeps one 4-wave workgroup per tile (A/B, compare tests)
     g_env.tp_one_slab = geti("SD_TP_ONE_SLAB", 1);    // 0: a shard's O / down projection keeps its k-slabs + the fold launch in front of the all-reduce (A/B)
@@ -272,7 +272,11 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
     static const int tiled_min = getenv("SD_GEMM_TILED_MIN") ? atoi(getenv("SD_GEMM_TILED_MIN")) : 65;
     // (65..SD_MAX_ROWS rows - 8 streams x 9 verify rows - stay on the balanced one-workgroup-per-CU kernel, with its fused
     //  epilogues, when both of its plans for the shape are good; prefill chunks of that size take it too)
-    const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= g_env.rows_max && rows_plan(N, K, M, fused).ok;
+    // (a k-slab GEMM - O / down projection - of a 113..144-row prefill pass is faster on gemm_bf16_mm: 18.1 / 36.2 us against
+    //  19.7 / 42.5 at 132 rows, tools/mm_bench.py; QKV and gate/up with their fused epilogues stay on the balanced kernel:
+    //  44.9 / 70.1 us against 50.1 / 74.7)
+    const bool mm_slabs = g_env.gemm_mm && !fused && M > 112 && (size_t)N * K >= ((size_t)16 << 20) && N / 16 / 8 < 64;
+    const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= g_env.rows_max && !mm_slabs && rows_plan(N, K, M, fused).ok;
     if (x_tiled && M >= tiled_min && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
         p.tiled = true;
         if (g_env.gemm_mm && Mpad > 64) {
@@ -289,7 +293,7 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
             if (g_env.mm_mtw) p.mtw = g_env.mm_mtw;
             const int blocks = blocks_of(p.mtw);
             int S = fused ? 1 : (g_env.mm_s ? g_env.mm_s : std::max(1, (G - G / 16 + blocks / 2) / blocks));
-            S = std::min(S, std::max(1, KS / 8));
+            S = std::min(std::min(S, 8), std::max(1, KS / 8));     // (every slab is a write + a read of Mpad x N floats)
             p.ksp = (int)align_up((KS + S - 1) / S, 2);
             p.S = (KS + p.ksp - 1) / p.ksp;
             return p;

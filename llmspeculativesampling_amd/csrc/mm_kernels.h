@@ -43,18 +43,19 @@ __device__ __forceinline__ void mm_glds16(const u32x4 *gsrc, unsigned lds_dst) {
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-// wait until at most `stages` stages of LPS requests each are outstanding (the immediate must be a literal)
-template <int LPS>
-__device__ __forceinline__ void mm_wait_stages(int stages) {
-    static_assert(LPS == 2 || LPS == 3 || LPS == 4 || LPS == 6, "requests per wave and stage");
-    switch (stages * LPS) {
+// wait until at most n of this wave's requests are outstanding (the immediate must be a literal)
+__device__ __forceinline__ void mm_wait_stages(int n) {
+    switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
@@ -92,16 +93,21 @@ __global__ __launch_bounds__(MM_THREADS) void gemm_bf16_mm(const u32x4 *__restri
     // cache policy costs no branch.  An m-tile past the buffer re-reads its last one (rows >= M, never stored).
     const u32x4 *src[LPS];
     unsigned slot[LPS];
+    bool have[LPS];                                               // (wave-uniform) an X tile past the buffer is not copied at all
+    int my_lps = 0;                                               // requests this wave makes per stage: its vmcnt unit
 #pragma unroll
     for (int r = 0; r < LPS; ++r) {
         if (r < KT) {
             slot[r] = (unsigned)(r * TT + wv);
             src[r] = Wp + ((size_t)(nt0 + wv) * KS + kb0 + r) * 64 + lane;
+            have[r] = true;
         } else {
             const int q = r - KT, kk = q / XPW, xi = wv + 8 * (q % XPW);
             slot[r] = (unsigned)(kk * TT + WT + xi);
+            have[r] = mt0 + xi < mt_end;
             src[r] = Xp + ((size_t)min(mt0 + xi, mt_end - 1) * KS + kb0 + kk) * 64 + lane;
         }
+        my_lps += have[r] ? 1 : 0;
     }
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)mm_smem);
     auto issue = [&](int stage, int buf) {                        // this wave's slots of k-stage `stage` -> buffer buf
@@ -111,8 +117,11 @@ __global__ __launch_bounds__(MM_THREADS) void gemm_bf16_mm(const u32x4 *__restri
 #pragma unroll
         for (int r = 0; r < LPS; ++r) {
             const unsigned dst = lds0 + ((unsigned)(buf * NL) + slot[r]) * 1024u;
-            if constexpr (WNT) { if (r < KT) mm_glds16<true>(src[r] + off, dst); else mm_glds16<false>(src[r] + off, dst); }
-            else mm_glds16<false>(src[r] + off, dst);
+            if (r < KT) {
+                if constexpr (WNT) mm_glds16<true>(src[r] + off, dst); else mm_glds16<false>(src[r] + off, dst);
+            } else if (have[r]) {
+                mm_glds16<false>(src[r] + off, dst);
+            }
         }
     };
 
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(MM_THREADS) void gemm_bf16_mm(const u32x4 *__restri
         if (p < nst) issue(p, p);
     int cur = 0, nxt = NBUF - 1;                                  // buffer of stage s, buffer of stage s + NBUF - 1
     for (int s = 0; s < nst; ++s) {
-        mm_wait_stages<LPS>(min(NBUF - 2, nst - 1 - s));          // own share of stage s has landed
+        mm_wait_stages(min(NBUF - 2, nst - 1 - s) * my_lps);      // own share of stage s has landed
         __builtin_amdgcn_s_barrier();                             // ... everybody's; and stage s - 1's buffer is free
         asm volatile("" ::: "memory");
         if (STAG && late && rows_here) mul();                     // stage s - 1 (zeros at s = 0)

@@ -76,18 +76,25 @@ if __name__ == "__main__":
             us = run(f"M={M} {name:8s} tiled", N, K, M, Wp, xt, ref)
             tot.setdefault("tiled", 0.0)
             tot["tiled"] += us or 0.0
+            if M <= 144:
+                setenv(SD_GEMM_ROWS_MAX=None)
+                us = run(f"M={M} {name:8s} rows (balanced kernel)", N, K, M, Wp, xt, ref)
+                tot.setdefault("rows", 0.0)
+                tot["rows"] += us or 0.0
+                setenv(SD_GEMM_ROWS_MAX=64)
             best = None
             for mtw in (4, 2):
                 if mtw == 2 and False:
                     continue
-                for S in ((0, 1, 2, 3, 4, 6, 8) if name != "gate_up" else (0, 1, 2)):
-                    for nt in (1, 0) if S == 0 else (1,):
-                        setenv(SD_GEMM_MM=1, SD_MM_MTW=mtw, SD_MM_S=S or None, SD_MM_NT=nt)
-                        us = run(f"M={M} {name:8s} mm mtw={mtw} S={S} nt={nt}", N, K, M, Wp, xt, ref)
+                for S in ((0, 1, 2, 3, 4, 6) if name != "gate_up" else (0, 1, 2)):
+                    for nt in (1,):
+                        setenv(SD_GEMM_MM=1, SD_MM_MTW=mtw, SD_MM_S=S or None)
+                        us = run(f"M={M} {name:8s} mm mtw={mtw} S={S}", N, K, M, Wp, xt, ref)
                         if us and (best is None or us < best):
                             best = us
             tot.setdefault("mm_best", 0.0)
             tot["mm_best"] += best or 0.0
             del W, Wp, x, xt, ref
             torch.cuda.empty_cache()
-        print(f"== M={M}: per layer tiled {tot['tiled']:.1f} us, mm (best per shape) {tot['mm_best']:.1f} us", flush=True)
+        print(f"== M={M}: per layer tiled {tot['tiled']:.1f} us, mm (best per shape) {tot['mm_best']:.1f} us" +
+              (f", balanced rows kernel {tot['rows']:.1f} us" if "rows" in tot else ""), flush=True)
