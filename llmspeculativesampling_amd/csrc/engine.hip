@@ -13,6 +13,7 @@
 #include "small_kernels.h"
 #include "rows_kernels.h"
 #include "mm_kernels.h"
+#include "prefill_attn.h"
 #include "fused_kernels.h"
 #include "normload_kernels.h"
 
@@ -156,7 +157,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, tiny_split_bytes = 24576, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_mm = 1, mm_mtw = 0, mm_s = 0;
+    int gemm_mm = 1, mm_mtw = 0, mm_s = 0, prefill_attn = 1;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
@@ -180,6 +181,7 @@ static void refresh_env() {
     g_env.fuse_attn_o = geti("SD_FUSE_ATTN_O", 1);    // 0: attention and the O projection as two launches (A/B runs, bit-compare tests)
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_mm = geti("SD_GEMM_MM", 1);            // 1 (default): prefill passes the balanced kernel does not take run on gemm_bf16_mm (mm_kernels.h) instead of gemm_bf16_tiled
+    g_env.prefill_attn = geti("SD_PREFILL_ATTN", 1);  // 0: prefill passes keep attn_kernel's 8-row groups (A/B runs, compare tests)
     g_env.mm_mtw = geti("SD_MM_MTW", 0);              // (sweeps) m-tiles per wave of gemm_bf16_mm: 2 = 128-row blocks, 4 = 256-row blocks; 0 = by row count
     g_env.mm_s = geti("SD_MM_S", 0);                  // (sweeps) k-slabs of gemm_bf16_mm; 0 = planned
 
@@ -1018,6 +1020,46 @@ static int run_gemm_fused(sd_session *s, const void *W, const void *X, int M, in
     return SD_OK;
 }
 
+// Prefill passes (rows = consecutive positions of a stream) of a 16-bit model with head_dim 128: 16-row groups, both products
+// on the matrix cores (prefill_attn.h).  Returns false when the pass does not qualify (the caller takes attn_kernel).
+#define PA_LDS_MAX (150 * 1024)
+static size_t prefill_attn_lds(int s_max) {
+    return (size_t)PA_ROWS * ((size_t)align_up(s_max, 64) + PA_SPAD) * sizeof(float) + (size_t)PA_VCH * PA_VST;
+}
+template <typename T>
+static bool prefill_attn_ok(const sd_session *s, const RowTab &tab, int s_max) {
+    if constexpr (sizeof(T) != 2) return false;
+    const sd_model_config &c = s->m->cfg;
+    return g_env.prefill_attn && tab.contig && !tab.tree && !tab.kv_fp8 && c.head_dim == 128 && tab.n_rows >= 32 &&
+           c.n_heads % c.n_kv_heads == 0 && prefill_attn_lds(s_max) <= PA_LDS_MAX;
+}
+template <typename T>
+static int launch_attn_prefill(sd_session *s, const T *q, const RowTab &tab, int layer, T *out, int s_max, hipStream_t st) {
+    const sd_model_config &c = s->m->cfg;
+    // the table's groups are <= ATT_TQ consecutive rows of a stream: two neighbours of one stream make a 16-row group
+    PaGroups pg = {};
+    for (int g = 0; g < tab.n_groups; ++g) {
+        const int i = pg.n;
+        const bool join = i > 0 && pg.nrows[i - 1] == ATT_TQ && tab.grp_stream[g] == tab.grp_stream[g - 1] &&
+                          tab.grp_row0[g] == pg.row0[i - 1] + ATT_TQ && tab.grp_pos[g] == pg.pos[i - 1] + ATT_TQ;
+        if (join) { pg.nrows[i - 1] += tab.grp_n[g]; continue; }
+        pg.row0[i] = tab.grp_row0[g]; pg.nrows[i] = tab.grp_n[g]; pg.pos[i] = tab.grp_pos[g];
+        pg.max_seq[i] = tab.max_seq[tab.grp_stream[g]]; pg.kv[i] = tab.kv_base[tab.grp_stream[g]];
+        ++pg.n;
+    }
+    const int s_cap = (int)align_up(s_max, 64);
+    const size_t lds = prefill_attn_lds(s_max);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(attn_prefill_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PA_LDS_MAX);
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_prefill_kernel<T>), dim3(c.n_heads, pg.n), dim3(256), lds, st, q, pg, layer, out, c.n_heads, c.n_kv_heads,
+                       c.arch, 1.0f / sqrtf((float)c.head_dim), s_cap);
+    return SD_OK;
+}
+
 // keys per workgroup above which a group's keys are cut over several workgroups (and merged by attn_combine_kernel)
 #define ATT_SPLIT_KEYS 384
 #define ATT_MAX_PARTS 64          // groups * splits the partial buffer is sized for
@@ -1503,7 +1545,7 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                                1.0f / sqrtf((float)D), c.n_heads, c.n_kv_heads, D, tab, l, qb, fused ? 1 : 0);
             SD_LAUNCH_CHECK();
         }
-        bool o_done = false, xn_o = false;
+        bool o_done = false, xn_o = false, attn_done = false;
         if constexpr (!std::is_same<T, float>::value) {
             if (attn_oproj_ok<T>(s, tab, s_max)) {
                 // the residual add in the O projection's epilogue, the norm in gate/up's operand load (no launch between)
@@ -1516,7 +1558,15 @@ static int forward_impl(sd_session *s, const RowTab &tab, int s_max, float *logi
                 o_done = true;
             }
         }
-        if (!o_done) {
+        if constexpr (!std::is_same<T, float>::value) {
+            if (!o_done && prefill_attn_ok<T>(s, tab, s_max)) {
+                ProfScope ps(s, PC_ATTN, st);
+                if ((rc = launch_attn_prefill<T>(s, qb, tab, l, at, s_max, st)) != SD_OK) return rc;
+                SD_LAUNCH_CHECK();
+                attn_done = true;
+            }
+        }
+        if (!o_done && !attn_done) {
             ProfScope ps(s, PC_ATTN, st);
             switch (D) {
                 case 16: rc = launch_attn<T, 16>(s, qb, tab, l, at, s_max, st); break;

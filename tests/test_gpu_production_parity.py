@@ -519,3 +519,52 @@ def test_prefill_pass_fp16_on_gemm_bf16_mm_vs_oracle(hip):
         print(f"fp16, {q}-row pass at position {pos}: |logit| max {scale:.2f}, max err {err:.4f}")
         assert err <= 0.005 * scale + 2e-3, (q, err, scale)
         pos += q
+
+
+@pytest.mark.parametrize("kind", ["llama", "llama_gqa", "opt"])
+def test_prefill_attention_on_the_matrix_cores_vs_fp32_truth_and_attn_kernel(hip, kind, monkeypatch):
+    """Prefill passes of >= 32 rows of a head_dim-128 model take attn_prefill_kernel (prefill_attn.h: 16-row groups, P.V by
+    MFMA over LDS-staged V read back transposed with ds_read_b64_tr_b16) instead of attn_kernel's 8-row groups.  Two passes of
+    ONE sequence - 200 rows from position 0, then 100 rows on top of them (keys 0..299: five V chunks, a ragged last group of
+    4 rows, a ragged last chunk) - for an MHA Llama, a GQA Llama (8 query heads on 2 KV heads) and an OPT shape (no score
+    scaling after the product, biases): the last 8 logit rows of each pass under the file's rule against the fp32 truth, and
+    against the same passes through attn_kernel (SD_PREFILL_ATTN=0) - same scores, same probabilities, only the order of the
+    P.V sum differs: within two bf16 ulps of the logit scale (measured: one - a handful of logits round the other way)."""
+    if kind == "opt":
+        cfg = ModelConfig(arch="opt", vocab_size=4096, hidden_size=1024, ffn_dim=4096, num_hidden_layers=2, num_attention_heads=8,
+                          num_key_value_heads=8, max_position_embeddings=512, do_layer_norm_before=True)
+    else:
+        cfg = ModelConfig(arch="llama", vocab_size=4096, hidden_size=1024, intermediate_size=2816, num_hidden_layers=2,
+                          num_attention_heads=8, num_key_value_heads=2 if kind == "llama_gqa" else 8, max_position_embeddings=512,
+                          rms_norm_eps=1e-5)
+    ids = torch.from_numpy(np.random.default_rng(7).integers(3, cfg.vocab_size, size=(1, 300)))
+
+    def soft_head(name, t):
+        return t * 0.125 if name.endswith("embed_tokens.weight") and kind == "opt" else t
+
+    def run(flag):
+        monkeypatch.setenv("SD_PREFILL_ATTN", flag)
+        m = hip.engine.SpecDecModel.synthetic(cfg, seed=17, dtype=torch.bfloat16, max_pos=320, transform=soft_head)
+        ses = m.new_session(320)
+        a = ses.forward(ids[0, :200].to(torch.int32).cuda(), 8).cpu().clone()
+        b = ses.forward(ids[0, 200:].to(torch.int32).cuda(), 8).cpu().clone()
+        kv = [t.float().cpu().clone() for t in ses.past_key_values()[1]]
+        return m, a, b, kv
+    m, a1, b1, kv1 = run("1")
+    sd16 = _host_sd(m)
+    del m
+    _, a0, b0, kv0 = run("0")
+    torch.cuda.empty_cache()
+    o16, o32 = oracle.RefCausalLM(cfg, sd16), oracle.RefCausalLM(cfg, {k: v.float() for k, v in sd16.items()})
+    r16, r32 = o16(ids).logits.float()[0], o32(ids).logits.float()[0]
+    for name, new, old, lo, hi in (("200-row pass", a1, a0, 192, 200), ("100-row pass at 200", b1, b0, 292, 300)):
+        ref16, truth = r16[lo:hi], r32[lo:hi]
+        e_hip, e_ref = float((new - truth).abs().max()), float((ref16 - truth).abs().max())
+        rms_hip, rms_ref = float((new - truth).pow(2).mean().sqrt()), float((ref16 - truth).pow(2).mean().sqrt())
+        d_old = float((new - old).abs().max())
+        print(f"{kind}, {name}: max err hip {e_hip:.4f} ref-bf16 {e_ref:.4f}; rms {rms_hip:.5f} / {rms_ref:.5f}; vs attn_kernel {d_old:.4f}")
+        _assert_within_reference_error((e_hip, e_ref, rms_hip, rms_ref), f"{kind}, {name}")
+        assert d_old <= 2.0 ** -6 * float(truth.abs().max()), (kind, name, d_old, float(truth.abs().max()))
+    # layer 0's K / V rows do not depend on attention at all: bit-identical; layer 1's only through one bf16 rounding of layer 0
+    for x1, x0 in zip(kv1, kv0):
+        assert float((x1 - x0).abs().max()) <= 0.05 * max(1.0, float(x0.abs().max()))
