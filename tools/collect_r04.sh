@@ -28,5 +28,7 @@ echo "[9b] lock-step tail A/B"; for mode in 0 1; do SD_BATCH_FUSED_TAIL=$mode ti
 echo "[9c] tp shard"; timeout -k 10 300 python tools/tp_shard_bench.py > $O/tp8_shard_one_gpu.txt 2>&1
 echo "[9d] small-path by grid"; bash tools/trace_cmd.sh r04/small_path_llama68m - tools/draft_step_bench.py --max-len 64 > /dev/null 2>&1; bash tools/trace_cmd.sh r04/small_path_opt125m - tools/draft_step_bench.py --draft opt-125m --max-len 64 > /dev/null 2>&1
 echo "[10] 70b"; timeout -k 10 500 python bench.py --target llama-2-70b --kv-dtype fp8 --steps 2 $B > $O/bench_llama70b_fp8kv_1gpu.json 2>/dev/null
-echo "[11] rows"; timeout -k 10 300 python tools/forward_rows_bench.py 5 9 16 40 64 72 127 132 256 > $O/forward_rows.txt 2>&1
+echo "[11] rows"; timeout -k 10 300 python tools/forward_rows_bench.py 5 9 16 40 64 72 127 132 150 200 256 > $O/forward_rows.txt 2>&1
+SD_GEMM_MM=0 SD_PREFILL_ATTN=0 timeout -k 10 300 python tools/forward_rows_bench.py 127 132 150 200 256 > $O/forward_rows_round3_prefill_path.txt 2>&1
+echo "[12] prefill GEMM sweep"; timeout -k 10 500 python tools/mm_bench.py 256 200 132 > $O/mm_gemm_sweep.txt 2>&1
 ls -la $O
