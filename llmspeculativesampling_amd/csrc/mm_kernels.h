@@ -156,6 +156,10 @@ __global__ __launch_bounds__(MM_THREADS) void gemm_bf16_mm(const u32x4 *__restri
     int cur = 0, nxt = NBUF - 1;                                  // buffer of stage s, buffer of stage s + NBUF - 1
     for (int s = 0; s < nst; ++s) {
         mm_wait_stages(min(NBUF - 2, nst - 1 - s) * my_lps);      // own share of stage s has landed
+        // (the late half carries stage s - 1's fragment reads across this barrier in flight; the buffer they read is the one the
+        //  next requests overwrite - the DMA lands hundreds of cycles later than an LDS read completes, but nothing ORDERS the
+        //  two, so the reads are retired here: by now they have had the whole wait above to finish)
+        if constexpr (STAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // ... everybody's; and stage s - 1's buffer is free
         asm volatile("" ::: "memory");
         if (STAG && late && rows_here) mul();                     // stage s - 1 (zeros at s = 0)
