@@ -274,14 +274,25 @@ __device__ __forceinline__ void gemm_epilogue_fold(FoldFn folded, int fs, float 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) x[c] = rnd<H>(r[c] + (e.bias ? to_f(e.bias[col + c]) : 0.f));
                 if (EPI == EPI_QKV_ROPE && (is_q || is_k)) {
+                    // the lane's four columns are dims d, d + hd, d + 1, d + 1 + hd (pair-interleaved weight rows), d even:
+                    // two 4-byte stores (dims d, d + 1 and d + hd, d + 1 + hd) instead of four 2-byte ones
+                    const int d0 = within >> 1;
+                    float o0[2], o1[2];
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        const int d = (within >> 1) + pr;
+                        const int d = d0 + pr;
                         const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
                         const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
-                        const float o0 = rnd<H>(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn)), o1 = rnd<H>(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
-                        if (kv8) { dst8[d] = to_fp8(o0, inv_sc); dst8[d + hd] = to_fp8(o1, inv_sc); }
-                        else { dst[d] = (H)o0; dst[d + hd] = (H)o1; }
+                        o0[pr] = rnd<H>(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn));
+                        o1[pr] = rnd<H>(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
+                    }
+                    if (kv8) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) { dst8[d0 + pr] = to_fp8(o0[pr], inv_sc); dst8[d0 + pr + hd] = to_fp8(o1[pr], inv_sc); }
+                    } else {
+                        const H lo[2] = {(H)o0[0], (H)o0[1]}, hi[2] = {(H)o1[0], (H)o1[1]};
+                        *reinterpret_cast<unsigned *>(dst + d0) = *reinterpret_cast<const unsigned *>(lo);
+                        *reinterpret_cast<unsigned *>(dst + d0 + hd) = *reinterpret_cast<const unsigned *>(hi);
                     }
                 } else {
                     if (EPI == EPI_QKV_PLAIN && is_q) {
