@@ -1,6 +1,8 @@
-// Many-row GEMM for prefill passes of 145..256 rows (and any shape the balanced kernel does not plan):
+// Many-row GEMM for prefill passes of 145..256 rows (and any shape the balanced kernel does not plan): the nn.Linear
+// projections of a decoder layer (reference sampling/models/modeling_llama.py:292-393, 405-457; modeling_opt.py:303-378) over
+// the rows of a prompt, as the reference's no-cache forward feeds them (kvcache_model.py:156):
 //
-//     part[sb][m][n] = sum_{k in slab sb} X[m][k] * W[n][k]
+//     part[sb][m][n] = sum_{k in slab sb} X[m][k] * W[n][k]        (or, with ONE slab, the fused QKV / SiLU / ReLU epilogue)
 //
 // gemm_bf16_tiled (model_kernels.h) moves every tile global -> registers -> LDS and synchronises the workgroup around each
 // 64-column k-step with nothing in flight across the barrier: 610-650 TFLOP/s at 256 rows (a quarter of the dense bf16
@@ -21,8 +23,8 @@
 //     stage's fragments in registers across the barrier and multiply them at the START of the next interval, while waves
 //     0-3 request and read; then 0-3 multiply while 4-7 request and read (MI355X_MICROARCH.md, two waves per SIMD, item 9);
 //     (+7-10 % at 256 rows, bit-identical sums);
-//   * ROT (measured: no gain, off): the blocks that share an XCD start at different points of their k-range and walk it cyclically, so that the
-//     ~30 CUs of an XCD do not all ask the L2 for the same activation lines in the same microsecond.  (The fp32 sums of a
+//   * ROT (measured: no gain, off): the blocks that share an XCD start at different points of their k-range and walk it
+//     cyclically, so that the ~30 CUs of an XCD do not all ask the L2 for the same activation lines in the same microsecond.  (The fp32 sums of a
 //     block then start at a different k: same values up to rounding order; the integer-exact tests hold either way.)
 // The weight tiles of a block whose rows are ALL in the block (one m-block) are read once chip-wide: non-temporal; with two
 // m-blocks the second reader should find them in L2 / the Infinity Cache: default policy (WNT = false).
