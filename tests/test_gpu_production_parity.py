@@ -152,7 +152,9 @@ def test_mfma_gemm_is_integer_exact_at_production_shapes(hip, shape):
     """W in {-2..2}, X in {-4..4} (exact in bf16): every product and every partial sum is an integer below 2^24, so the
     fp32 result is the same in any summation order and the kernels - MFMA accumulation, in-workgroup fold, split-K slabs
     and their reduction - must equal an integer matmul bit for bit.  Row counts cover every dispatch class of
-    sd_gemm_bf16: 1, 5 (decode / verify), 16, 17, 40, 60, 64 (stream-batched verify), 128 and 256 (prefill chunks)."""
+    sd_gemm_bf16: 1, 5 (decode / verify), 16, 17, 40, 60, 64 (stream-batched verify), 128 and 256 (prefill chunks); 145-256 rows
+    are gemm_bf16_mm's k-slab form (mm_kernels.h) - 256 a full 256-row block, 145 / 150 / 177 / 200 / 241 ragged ones, whose X
+    tiles past the pass are not copied and whose waves count their own LDS-DMA requests."""
     N, K = GEMM_SHAPES[shape]
     g = torch.Generator(device="cuda").manual_seed(N + K)
     W = torch.randint(-2, 3, (N, K), device="cuda", generator=g).to(torch.bfloat16)
@@ -160,7 +162,7 @@ def test_mfma_gemm_is_integer_exact_at_production_shapes(hip, shape):
     assert hip.lib.sd_pack_weight_bf16(W.data_ptr(), Wp.data_ptr(), N, K, _st()) == 0
     Wf = W.double()
     part = torch.empty(64 * 64 * N if N <= 8192 else 20 * 256 * N, dtype=torch.float32, device="cuda")
-    for M in (1, 5, 16, 17, 40, 60, 64, 72, 80, 96, 127, 128, 132, 144, 256):
+    for M in (1, 5, 16, 17, 40, 60, 64, 72, 80, 96, 127, 128, 132, 144, 145, 150, 177, 200, 241, 256):
         X = torch.randint(-4, 5, (M, K), device="cuda", generator=g).to(torch.bfloat16)
         Xt = torch.zeros((M + 15) // 16 * 16 * K, device="cuda", dtype=torch.bfloat16)
         assert hip.lib.sd_pack_activation_bf16(X.data_ptr(), Xt.data_ptr(), M, K, _st()) == 0
