@@ -278,10 +278,13 @@ __device__ __forceinline__ void gemm_epilogue_fold(FoldFn folded, int fs, float 
                     // two 4-byte stores (dims d, d + 1 and d + hd, d + 1 + hd) instead of four 2-byte ones
                     const int d0 = within >> 1;
                     float o0[2], o1[2];
+                    // (cos / sin of dims d0, d0 + 1: one 4-byte load each - d0 and pos * hd are even)
+                    H c2[2], s2[2];
+                    *reinterpret_cast<unsigned *>(c2) = *reinterpret_cast<const unsigned *>(e.cos_t + (size_t)pos * hd + d0);
+                    *reinterpret_cast<unsigned *>(s2) = *reinterpret_cast<const unsigned *>(e.sin_t + (size_t)pos * hd + d0);
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        const int d = d0 + pr;
-                        const float cs = to_f(e.cos_t[(size_t)pos * hd + d]), sn = to_f(e.sin_t[(size_t)pos * hd + d]);
+                        const float cs = to_f(c2[pr]), sn = to_f(s2[pr]);
                         const float x0 = x[2 * pr], x1 = x[2 * pr + 1];
                         o0[pr] = rnd<H>(rnd<H>(x0 * cs) + rnd<H>(-x1 * sn));
                         o1[pr] = rnd<H>(rnd<H>(x1 * cs) + rnd<H>(x0 * sn));
