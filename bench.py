@@ -72,6 +72,23 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+class _stdout_to_stderr:
+    """Native libraries (gloo's "[Gloo] Rank 0 is connected to ..." lines) print on file descriptor 1 while a process group is set
+    up; the contract is ONE JSON line on stdout, so fd 1 points at stderr for that span."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: spawn the N ranks (fresh interpreters, one per GPU, RCCL
     rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, and wait for them.  Rank 0 prints the
@@ -111,8 +128,9 @@ def stub_worker(args, rank, world):
     if os.environ.get("SPECDEC_BENCH_STUB_FAIL_RANK") == str(rank):
         return 3                                     # launcher test: a rank that dies before the rendezvous
     if world > 1:
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        dist.barrier()
+        with _stdout_to_stderr():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
     t0 = time.time()
     outs, new_tokens = [], 0
     for i in range(args.steps):
@@ -329,7 +347,9 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.barrier()                             # (the first collective: connections are made here)
 
     from llmspeculativesampling_amd.config import load_config
     from llmspeculativesampling_amd.engine import SpecDecModel
