@@ -157,7 +157,7 @@ extern "C" int sd_pack_weight_bf16(const void *src, void *dst, int N, int K, voi
 struct EnvTun {
     int gemm_ntw = 4, gemm_units = -1, small_path = 1, small_split_bytes = 0, tiny_split_bytes = 24576, fuse_embed_qkv = 1, head_tiles = 1;
     int attn_split_keys = 384, attn_keys_per_split = 256;
-    int gemm_mm = 1, mm_mtw = 0, mm_s = 0, prefill_attn = 1;
+    int gemm_mm = 1, mm_mtw = 0, mm_s = 0, prefill_attn = 1, mm_slabs_min = 24;
     int wide_qkv = 1, tp_one_slab = 1, gemm_rows = 1, cus = 0, fuse_attn_o = 1, ao_stamps = 0, ao_delay = 300, ao_gap = 100, norm_on_load = 2, rows_max = SD_ROWS_MAX;
 };
 static EnvTun g_env;
@@ -182,6 +182,7 @@ static void refresh_env() {
     g_env.norm_on_load = geti("SD_NORM_ON_LOAD", 2);  // 0: residual+norm launches stay; 1: attention -> MLP seam only; 2: both seams (A/B runs, compare tests)
     g_env.gemm_mm = geti("SD_GEMM_MM", 1);            // 1 (default): prefill passes the balanced kernel does not take run on gemm_bf16_mm (mm_kernels.h) instead of gemm_bf16_tiled
     g_env.prefill_attn = geti("SD_PREFILL_ATTN", 1);  // 0: prefill passes keep attn_kernel's 8-row groups (A/B runs, compare tests)
+    g_env.mm_slabs_min = geti("SD_MM_SLABS_MIN", 24); // rows from which the k-slab GEMMs (O / down) of a pass take gemm_bf16_mm instead of the balanced kernel
     g_env.mm_mtw = geti("SD_MM_MTW", 0);              // (sweeps) m-tiles per wave of gemm_bf16_mm: 2 = 128-row blocks, 4 = 256-row blocks; 0 = by row count
     g_env.mm_s = geti("SD_MM_S", 0);                  // (sweeps) k-slabs of gemm_bf16_mm; 0 = planned
 
@@ -274,14 +275,16 @@ static GemmPlan gemm_plan(int N, int K, int M, bool x_tiled = true, bool fused =
     static const int tiled_min = getenv("SD_GEMM_TILED_MIN") ? atoi(getenv("SD_GEMM_TILED_MIN")) : 65;
     // (65..SD_MAX_ROWS rows - 8 streams x 9 verify rows - stay on the balanced one-workgroup-per-CU kernel, with its fused
     //  epilogues, when both of its plans for the shape are good; prefill chunks of that size take it too)
-    // (a k-slab GEMM - O / down projection - of a 113..144-row prefill pass is faster on gemm_bf16_mm: 18.1 / 36.2 us against
-    //  19.7 / 42.5 at 132 rows, tools/mm_bench.py; QKV and gate/up with their fused epilogues stay on the balanced kernel:
-    //  44.9 / 70.1 us against 50.1 / 74.7)
-    const bool mm_slabs = g_env.gemm_mm && !fused && M > 112 && (size_t)N * K >= ((size_t)16 << 20) && N / 16 / 8 < 64;
+    // (a k-slab GEMM - O / down projection - of a 24..144-row pass is faster on gemm_bf16_mm with 128-row blocks and 6 slabs
+    //  than on the balanced kernel - 12.7 / 28.1 us against 15.3 / 29.6 at 40 rows (8 streams x 5), 13.6 / 28.3 against 16.7 /
+    //  31.6 at 60, 14.7 / 30.2 against 18.0 / 36.3 at 80, 18.1 / 36.2 against 19.7 / 42.5 at 132; equal at 24 - tools/mm_bench.py.
+    //  QKV and gate/up with their fused epilogues stay on the balanced kernel: 36.9 / 56.1 us against 52.0 / 60.5 at 80 rows,
+    //  44.9 / 70.1 against 50.1 / 74.7 at 132)
+    const bool mm_slabs = g_env.gemm_mm && !fused && M >= g_env.mm_slabs_min && (size_t)N * K >= ((size_t)16 << 20) && N / 16 / 8 < 64;
     const bool rows_take = M > SD_STREAM_MAX_ROWS && M <= g_env.rows_max && !mm_slabs && rows_plan(N, K, M, fused).ok;
-    if (x_tiled && M >= tiled_min && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
+    if (x_tiled && (M >= tiled_min || mm_slabs) && !rows_take && (N / 16) % 8 == 0 && KS % 2 == 0 && KS >= 16) {
         p.tiled = true;
-        if (g_env.gemm_mm && Mpad > 64) {
+        if (g_env.gemm_mm && (Mpad > 64 || mm_slabs)) {
             // gemm_bf16_mm (mm_kernels.h): 256-row blocks (mtw 4) or 128-row blocks (mtw 2) x 128 columns.  Fused (the caller
             // wants the whole k-range per block for a QKV / activation epilogue): the block shape that fills the CUs better
             // (13b at 256 rows: gate/up 216 blocks of 256 rows, QKV 240 blocks of 128).  Otherwise 256-row blocks past 128

@@ -72,12 +72,12 @@ if __name__ == "__main__":
         tot = {}
         for name, (N, K) in SHAPES.items():
             W, Wp, x, xt, ref = make(N, K, M)
-            setenv(SD_GEMM_MM=0, SD_MM_MTW=None, SD_MM_S=None, SD_MM_NT=None, SD_GEMM_ROWS_MAX=64)
+            setenv(SD_GEMM_MM=0, SD_MM_MTW=None, SD_MM_S=None, SD_MM_NT=None, SD_GEMM_ROWS_MAX=64, SD_MM_SLABS_MIN=1000)
             us = run(f"M={M} {name:8s} tiled", N, K, M, Wp, xt, ref)
             tot.setdefault("tiled", 0.0)
             tot["tiled"] += us or 0.0
             if M <= 144:
-                setenv(SD_GEMM_ROWS_MAX=None)
+                setenv(SD_GEMM_ROWS_MAX=None, SD_GEMM_MM=1)      # (the engine's default planner without the k-slab GEMMs on gemm_bf16_mm)
                 us = run(f"M={M} {name:8s} rows (balanced kernel)", N, K, M, Wp, xt, ref)
                 tot.setdefault("rows", 0.0)
                 tot["rows"] += us or 0.0
@@ -88,7 +88,7 @@ if __name__ == "__main__":
                     continue
                 for S in ((0, 1, 2, 3, 4, 6) if name != "gate_up" else (0, 1, 2)):
                     for nt in (1,):
-                        setenv(SD_GEMM_MM=1, SD_MM_MTW=mtw, SD_MM_S=S or None)
+                        setenv(SD_GEMM_MM=1, SD_MM_MTW=mtw, SD_MM_S=S or None, SD_MM_SLABS_MIN=1)
                         us = run(f"M={M} {name:8s} mm mtw={mtw} S={S}", N, K, M, Wp, xt, ref)
                         if us and (best is None or us < best):
                             best = us
