@@ -118,22 +118,26 @@ __global__ __launch_bounds__(GR_THREADS) void gemm_bf16_rows(const u32x4 *__rest
         // A k-step past the wave's range is not requested and multiplied as ZERO against the panel tile it meets (which
         // holds finite values: the loader clamps); every operand register is written on every path.
         u32x4 w[WB];
-        for (int c = 0; c < nch; ++c) {
-            bar();                                                // chunk c's panel is in LDS
-            if (c % WBM == 0) {
-                const int k0 = c * CH;
-                if (k0 + WB <= nk) {                              // a whole burst: WB back-to-back requests, no branch between
+        auto burst = [&](int c) {
+            const int k0 = c * CH;
+            if (k0 + WB <= nk) {                                  // a whole burst: WB back-to-back requests, no branch between
 #pragma unroll
-                    for (int u = 0; u < WB; ++u)
-                        w[u] = (probe & 8) ? u32x4{0u, 0u, 0u, 0u} : __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
-                } else {
+                for (int u = 0; u < WB; ++u)
+                    w[u] = (probe & 8) ? u32x4{0u, 0u, 0u, 0u} : __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
+            } else {
 #pragma unroll
-                    for (int u = 0; u < WB; ++u) {
-                        w[u] = u32x4{0u, 0u, 0u, 0u};
-                        if (k0 + u < nk && !(probe & 8)) w[u] = __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
-                    }
+                for (int u = 0; u < WB; ++u) {
+                    w[u] = u32x4{0u, 0u, 0u, 0u};
+                    if (k0 + u < nk && !(probe & 8)) w[u] = __builtin_nontemporal_load(wp + (size_t)(k0 + u) * 64);
                 }
             }
+        };
+        // the FIRST burst does not wait for the panel: weights do not depend on the activations, so they are requested in front
+        // of the first barrier and travel while the loader's first chunk lands (the launch's fill: one memory latency, not two)
+        burst(0);
+        for (int c = 0; c < nch; ++c) {
+            bar();                                                // chunk c's panel is in LDS
+            if (c > 0 && c % WBM == 0) burst(c);
             const int pbuf = (c & 1) * nwk + kg;
             const int wb0 = (c % WBM) * CH;
 #pragma unroll
